@@ -1,0 +1,177 @@
+/*
+ * radargrid_hip.h -- C ABI of libradargrid_hip.so (MI355X / gfx950 HIP kernels for the radar_grid hot path).
+ *
+ * The reference (jgmarti84/radar-processor) is pure Python/NumPy: it has no FFI, plugin or operator
+ * interface for this path.  The drop-in boundary is therefore the Python function surface of
+ * `radar_grid` (src/radar_grid/__init__.py:39-82), and this header is the native layer directly beneath
+ * it.  Each entry point names the reference code it replaces (paths relative to /root/reference/).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter name ends in `_host`;
+ *   - the caller owns every buffer; no entry point allocates, frees or synchronises;
+ *   - all work is enqueued on the caller's `hipStream_t` (passed as void*), so calls are graph-capturable;
+ *   - return value: RG_OK (0) or a negative rg_status; rg_last_error() gives a thread-local message;
+ *   - float32 device arrays read with 16-byte vector loads must be 16-byte aligned (RG_EALIGN otherwise);
+ *   - no global mutable state: entry points are thread-safe per stream.
+ *
+ * Data layout in HBM
+ *   gates      flat ray-major index g = (sweep*n_az + iaz)*n_gates + k   (radar_grid/utils.py:35-37)
+ *   voxels     z-major flat index v = (iz*ny + iy)*nx + ix               (radar_grid/compute.py:188-190,257-258)
+ *   CSR        indptr[V+1] (int32 or int64), gate_idx int32[P], weights float32[P]  (radar_grid/geometry.py:46-52)
+ *   packed fields  float32 [G][stride], stride in {1,2,4,8}: slot f of gate g holds field f's value, or the
+ *              EXCLUDED sentinel when the gate is masked/filtered for that field, so that the gather in
+ *              rg_csr_apply_f32 needs ONE load per pair for all fields (mask folded into the value).
+ */
+#ifndef RADARGRID_HIP_H
+#define RADARGRID_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RG_VERSION 100 /* 0.1.0 */
+#define RG_MAX_FIELDS 8
+
+typedef void* rg_stream_t; /* hipStream_t */
+
+typedef enum rg_status {
+  RG_OK = 0,
+  RG_EINVAL = -1,       /* bad argument (null pointer, negative size, unknown enum) */
+  RG_EALIGN = -2,       /* a vector-loaded buffer is not 16-byte aligned */
+  RG_ELAUNCH = -3,      /* hipGetLastError() after a launch */
+  RG_EWORKSPACE = -4,   /* workspace too small */
+  RG_EUNSUPPORTED = -5, /* e.g. n_fields > RG_MAX_FIELDS */
+  RG_ENODEVICE = -6     /* no HIP device visible */
+} rg_status;
+
+/* Quiet-NaN bit pattern that marks "gate excluded for this field" inside packed fields.  A data NaN that
+ * is NOT masked keeps its own payload and propagates like in NumPy (interpolate.py:78-82). */
+#define RG_EXCLUDED_BITS 0x7FD1CE5Du
+
+int rg_version(void);
+const char* rg_last_error(void);
+/* number of visible HIP devices, or RG_ENODEVICE */
+int rg_device_count(void);
+
+/* ---------------------------------------------------------------------------------------------------
+ * a1  antenna -> Cartesian (PyART antenna_vectors_to_cartesian, call sites radar_grid/utils.py:35-37).
+ * float64 math, float32 stores.  x,y,z are [n_rays][n_gates] ray-major.
+ * ------------------------------------------------------------------------------------------------- */
+int rg_antenna_to_cartesian_f32(const double* ranges_m, int32_t n_gates,
+                                const double* az_deg, const double* el_deg, int32_t n_rays,
+                                float* x, float* y, float* z, rg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * a3  GateFilter predicates (radar_grid/filters.py:114-258): mask_inout[g] |= pred(data[g]).
+ * NaN compares false, so threshold filters never exclude NaN gates (filters.py:134).
+ * ------------------------------------------------------------------------------------------------- */
+typedef enum rg_gate_op {
+  RG_GATE_BELOW = 0,   /* data <  a            filters.py:134 */
+  RG_GATE_ABOVE = 1,   /* data >  a            filters.py:157 */
+  RG_GATE_BETWEEN = 2, /* a < data < b         filters.py:182 */
+  RG_GATE_OUTSIDE = 3, /* data < a || data > b filters.py:207 */
+  RG_GATE_EQUAL = 4,   /* |data - a| < b       filters.py:232 */
+  RG_GATE_INVALID = 5  /* NaN or Inf           filters.py:257 */
+} rg_gate_op;
+
+int rg_gate_mask_f32(const float* data, int64_t n_gates, int32_t op, float a, float b,
+                     uint8_t* mask_inout, rg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * a2/a8 prologue  mask merge (radar_grid/interpolate.py:59-64) folded into the field values.
+ *   packed[g*stride + f] = (masks_host[f] && masks_host[f][g]) || (shared_mask && shared_mask[g])
+ *                          ? EXCLUDED : fields_host[f][g]          for f <  n_fields
+ *                          = EXCLUDED                               for f >= n_fields (padding slots)
+ * fields_host / masks_host are HOST arrays of n_fields DEVICE pointers (mask entries may be NULL).
+ * ------------------------------------------------------------------------------------------------- */
+int rg_pack_fields_f32(int32_t n_fields, const float* const* fields_host, const uint8_t* const* masks_host,
+                       const uint8_t* shared_mask, int64_t n_gates, int32_t stride, float* packed,
+                       rg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * a8/a9  K1 csr_apply: replaces radar_grid/interpolate.py:69-104 (apply_geometry) and the per-field loop
+ * of :137-140 (apply_geometry_multi) with ONE pass over the CSR for all n_fields field-volumes.
+ *   out[f*n_vox + v] = sum_j w_j*val_f(g_j) / sum_j w_j   over pairs j of row v whose gate is not EXCLUDED
+ *                      for field f, if that weight sum is > 0; otherwise fill_value.
+ * Products are float32 (as in the reference), sums are accumulated in float64 and rounded once.
+ * gate indices are clamped to [0, n_gates) before the gather (a corrupt index cannot fault the GPU).
+ * ------------------------------------------------------------------------------------------------- */
+int rg_csr_apply_f32(const void* indptr, int32_t indptr_is_i64, const int32_t* gate_idx, const float* weights,
+                     int64_t n_vox, int64_t n_pairs,
+                     const float* packed, int32_t n_fields, int32_t stride, int64_t n_gates,
+                     float fill_value, float* out, rg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * a11  K3 column reduce: radar_grid/products.py:488-490 (nanmax), :533-535 (nanmin), :578-580 (nanmean)
+ * over levels z_lo..z_hi (inclusive, already clipped by the caller as products.py:484-485 does).
+ * out_arg (optional, MAX/MIN only): first level attaining the extremum, -1 for an all-NaN column
+ * (np.nanargmax order; build-defined).
+ * ------------------------------------------------------------------------------------------------- */
+typedef enum rg_column_op { RG_COL_MAX = 0, RG_COL_MIN = 1, RG_COL_MEAN = 2 } rg_column_op;
+
+int rg_column_reduce_f32(const float* grid, int32_t nz, int64_t n_xy, int32_t z_lo, int32_t z_hi, int32_t op,
+                         float* out, int32_t* out_arg, rg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * a10  K4 CAPPI lerp: radar_grid/products.py:406-412.  out = fl32(fl32(w_lo*lo) + fl32(w_hi*hi)), the
+ * float32 arithmetic NumPy >= 2 performs with weak Python-float weights; NaN in either level -> NaN.
+ * The scalar control flow (products.py:361-404) stays on the host.
+ * ------------------------------------------------------------------------------------------------- */
+int rg_cappi_lerp_f32(const float* grid, int64_t n_xy, int32_t k_lo, float w_lo, float w_hi, float* out,
+                      rg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * a6/a7  geometry builder: replaces radar_grid/compute.py:18-103 (_process_single_level) and the merge of
+ * :232-272.  Membership and weights are evaluated in float64 from the float32 inputs with FP contraction
+ * disabled, i.e. the reference's arithmetic: valid gate (fl32(z - radar_altitude) <= toa), d2 < r2,
+ * r = max(min_radius, sqrt(x^2+y^2+z^2)*beam_factor).
+ *
+ * Search structure (build-specific): gates are bucketed into a uniform (x,y) cell grid and stably sorted
+ * by cell, so every cell row is one contiguous run of `sorted_gates`; a wavefront tests a voxel's runs
+ * 64 gates at a time.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct rg_cellgrid {
+  double x0, y0;         /* lower corner of cell (0,0) */
+  double inv_cx, inv_cy; /* 1 / cell size */
+  double z_lo, z_hi;     /* gates with z_rel outside [z_lo, z_hi] cannot reach any voxel and are dropped */
+  int32_t ncx, ncy;
+} rg_cellgrid;
+
+typedef struct rg_gate4 { float x, y, z; int32_t index; } rg_gate4; /* 16 bytes: one dwordx4 per candidate */
+
+typedef enum rg_weighting { RG_W_BARNES2 = 0, RG_W_CRESSMAN = 1, RG_W_NEAREST = 2 } rg_weighting;
+
+/* bytes of scratch rg_geom_bin_gates_f32 needs for n_gates gates */
+int64_t rg_geom_bin_workspace_bytes(int64_t n_gates, int32_t ncx, int32_t ncy);
+
+/* sorted_gates[0 .. n_binned) in (cell, gate index) order (buffer of n_gates records);
+ * cell_start[ncx*ncy + 1], with cell_start[ncx*ncy] = n_binned = number of gates that were kept */
+int rg_geom_bin_gates_f32(const float* gate_x, const float* gate_y, const float* gate_z, int64_t n_gates,
+                          float radar_altitude, float toa, const rg_cellgrid* cells_host,
+                          rg_gate4* sorted_gates, int32_t* cell_start,
+                          void* workspace, int64_t workspace_bytes, rg_stream_t stream);
+
+/* counts[v] = number of gates within voxel v's radius of influence; xc/yc/zc are the float32 linspace
+ * coordinate tables of radar_grid/compute.py:184-186 (device pointers). */
+int rg_geom_count_f32(const rg_gate4* sorted_gates, const int32_t* cell_start, const rg_cellgrid* cells_host,
+                      const float* xc, const float* yc, const float* zc, int32_t nz, int32_t ny, int32_t nx,
+                      double min_radius, double beam_factor, int32_t* counts, rg_stream_t stream);
+
+/* indptr[0..n] = exclusive prefix sum of counts[0..n) widened to int64 (indptr[n] = total pairs) */
+int64_t rg_scan_workspace_bytes(int64_t n);
+int rg_scan_counts_i64(const int32_t* counts, int64_t n, int64_t* indptr, void* workspace,
+                       int64_t workspace_bytes, rg_stream_t stream);
+
+/* second pass: writes gate_idx / weights of every row at indptr[v].. in (cell row, gate index) order */
+int rg_geom_fill_f32(const rg_gate4* sorted_gates, const int32_t* cell_start, const rg_cellgrid* cells_host,
+                     const float* xc, const float* yc, const float* zc, int32_t nz, int32_t ny, int32_t nx,
+                     double min_radius, double beam_factor, int32_t weighting, const int64_t* indptr,
+                     int32_t* gate_idx, float* weights, rg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RADARGRID_HIP_H */

@@ -1,0 +1,326 @@
+"""CPU oracle for the radar_grid hot path -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A NumPy restatement of the reference's algorithm for the path named by BASELINE.json
+(`radar_grid` geometry build -> CSR apply -> CAPPI / COLMAX).  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this module; the product
+package (``radar_processor_amd``) never does and fails loudly when its HIP library is missing.
+
+Pinning: every function here is checked in ``tests/test_oracle_golden.py`` against
+ (1) the literal known answers of the reference's own tests
+     (``tests/test_radar_grid_interpolate.py:75-93,116-153,218-317``,
+      ``tests/test_radar_grid_products.py:190-226,299-357``), and
+ (2) golden vectors produced by importing the reference's modules in the build container
+     (``tests/golden/make_golden.py``; NumPy/SciPy versions are recorded inside each fixture because the
+     reference's float32-vs-float64 intermediates depend on NEP-50).
+
+Each function cites the reference lines it restates (paths relative to /root/reference/).
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+EARTH_RADIUS = 6371000.0            # src/radar_grid/products.py:19
+EFFECTIVE_RADIUS_FACTOR = 4.0 / 3.0  # src/radar_grid/products.py:20
+
+
+# --------------------------------------------------------------------------------------------------
+# grid coordinates
+# --------------------------------------------------------------------------------------------------
+def axis_coords_f32(lo: float, hi: float, n: int) -> np.ndarray:
+    """Voxel-centre coordinates along one axis, exactly as src/radar_grid/compute.py:184-186:
+    float64 ``lo + i*step`` (NumPy's linspace, endpoint pinned to ``hi``) rounded once to float32."""
+    return np.linspace(lo, hi, n, dtype="float32")
+
+
+# --------------------------------------------------------------------------------------------------
+# geometry builder (src/radar_grid/compute.py:18-103 and :179-193)
+# --------------------------------------------------------------------------------------------------
+def gate_validity(gate_z: np.ndarray, radar_altitude: float, toa: float) -> Tuple[np.ndarray, np.ndarray]:
+    """compute.py:182 and :193 -- ``gate_z - radar_altitude`` is evaluated in the dtype of ``gate_z``
+    (float32 with a weak Python scalar under NumPy >= 2) and compared ``<= toa``."""
+    z_rel = gate_z - radar_altitude
+    return z_rel, z_rel <= toa
+
+
+def build_geometry(gate_x, gate_y, gate_z, grid_shape, grid_limits, radar_altitude=0.0,
+                   min_radius=250.0, beam_factor=0.01746, weighting="barnes2", toa=17000.0,
+                   chunk_pairs: int = 8_000_000):
+    """Brute-force restatement of ``compute_grid_geometry`` (compute.py:106-284).
+
+    Membership is the reference's: gate valid (``z_rel <= toa``) and ``d2 < r2`` with everything in
+    float64 computed from float32-rounded gate and voxel coordinates, ``d2 = dx*dx + dy*dy + dz*dz``
+    (compute.py:69-74), ``r = max(min_radius, sqrt(x^2+y^2+z^2) * beam_factor)`` (compute.py:46-47).
+    The cKDTree closed-ball query (compute.py:60) is a superset of the strict test, so it does not
+    change the set.  Weights follow compute.py:82-87.
+
+    Rows are returned sorted by ascending gate index (the reference's order is KD-tree traversal order;
+    tests canonicalise both before comparing).  Returns ``(indptr int64[V+1], gate_indices int32[P],
+    weights float32[P])``.
+
+    Intended for small grids / windows: gates are pre-filtered to the grid's bounding box grown by the
+    largest ROI, then tested densely in chunks.
+    """
+    if weighting not in ("barnes2", "cressman", "nearest"):
+        raise ValueError(f"Unknown weighting function: {weighting}")
+    nz, ny, nx = grid_shape
+    zc = axis_coords_f32(grid_limits[0][0], grid_limits[0][1], nz).astype(np.float64)
+    yc = axis_coords_f32(grid_limits[1][0], grid_limits[1][1], ny).astype(np.float64)
+    xc = axis_coords_f32(grid_limits[2][0], grid_limits[2][1], nx).astype(np.float64)
+
+    z_rel, valid = gate_validity(np.asarray(gate_z), radar_altitude, toa)
+    gx = np.asarray(gate_x).astype(np.float64)
+    gy = np.asarray(gate_y).astype(np.float64)
+    gz = np.asarray(z_rel).astype(np.float64)
+
+    # largest ROI over the grid is reached at a corner
+    cx = max(abs(xc[0]), abs(xc[-1])); cy = max(abs(yc[0]), abs(yc[-1])); cz = max(abs(zc[0]), abs(zc[-1]))
+    rmax = max(min_radius, np.sqrt(cx * cx + cy * cy + cz * cz) * beam_factor) * (1.0 + 1e-9) + 1e-6
+    near = (valid
+            & (gx >= xc.min() - rmax) & (gx <= xc.max() + rmax)
+            & (gy >= yc.min() - rmax) & (gy <= yc.max() + rmax)
+            & (gz >= zc.min() - rmax) & (gz <= zc.max() + rmax))
+    cand = np.nonzero(near)[0]            # ascending gate index
+    cgx, cgy, cgz = gx[cand], gy[cand], gz[cand]
+
+    n_vox = nz * ny * nx
+    counts = np.zeros(n_vox, dtype=np.int64)
+    idx_parts, w_parts = [], []
+    yy, xx = np.meshgrid(yc, xc, indexing="ij")
+    vy_level = yy.ravel(); vx_level = xx.ravel()
+    rows_per_chunk = max(1, chunk_pairs // max(1, cand.size))
+    for iz in range(nz):
+        vz = zc[iz]
+        dist = np.sqrt(vx_level ** 2 + vy_level ** 2 + np.full(vx_level.shape, vz) ** 2)
+        roi = np.maximum(min_radius, dist * beam_factor)
+        r2_level = roi * roi
+        for s in range(0, ny * nx, rows_per_chunk):
+            e = min(ny * nx, s + rows_per_chunk)
+            if cand.size == 0:
+                continue
+            dx = cgx[None, :] - vx_level[s:e, None]
+            dy = cgy[None, :] - vy_level[s:e, None]
+            dz = cgz[None, :] - vz
+            d2 = dx * dx + dy * dy + dz * dz
+            r2 = r2_level[s:e, None]
+            hit = d2 < r2
+            rr, cc = np.nonzero(hit)       # row-major => per voxel, ascending candidate (= gate) order
+            if rr.size == 0:
+                continue
+            counts[iz * ny * nx + s: iz * ny * nx + e] = np.bincount(rr, minlength=e - s)
+            d2h = d2[rr, cc]
+            r2h = np.broadcast_to(r2, d2.shape)[rr, cc]
+            if weighting == "barnes2":
+                w = (np.exp(-d2h / (r2h / 4)) + 1e-5).astype("float32")
+            elif weighting == "cressman":
+                w = ((r2h - d2h) / (r2h + d2h)).astype("float32")
+            else:
+                w = np.ones(d2h.shape[0], dtype="float32")
+            idx_parts.append(cand[cc].astype(np.int32))
+            w_parts.append(w)
+    indptr = np.zeros(n_vox + 1, dtype=np.int64)
+    np.cumsum(counts, out=indptr[1:])
+    gate_indices = np.concatenate(idx_parts) if idx_parts else np.zeros(0, dtype=np.int32)
+    weights = np.concatenate(w_parts) if w_parts else np.zeros(0, dtype=np.float32)
+    return indptr, gate_indices, weights
+
+
+def canonical_rows(indptr, gate_indices, weights):
+    """Sort every CSR row by gate index (stable) so two builders with different in-row order compare."""
+    indptr = np.asarray(indptr, dtype=np.int64)
+    n_rows = indptr.shape[0] - 1
+    row_of = np.repeat(np.arange(n_rows, dtype=np.int64), np.diff(indptr))
+    order = np.lexsort((np.asarray(gate_indices), row_of))
+    return indptr, np.asarray(gate_indices)[order], np.asarray(weights)[order]
+
+
+# --------------------------------------------------------------------------------------------------
+# CSR apply (src/radar_grid/interpolate.py:69-104) -- THE hot loop, also the timed CPU baseline
+# --------------------------------------------------------------------------------------------------
+def csr_apply(indptr, gate_indices, weights, field_values, field_mask, grid_shape,
+              fill_value=np.nan) -> np.ndarray:
+    """Masked weighted mean per voxel, in the reference's arithmetic: excluded gates contribute zero to
+    both sums (interpolate.py:78-79), products and segment sums are float32 under NumPy >= 2
+    (interpolate.py:82,92-93), a voxel is filled when its weight sum is > 0
+    (interpolate.py:100-102), otherwise it gets ``fill_value`` (interpolate.py:99)."""
+    indptr = np.asarray(indptr)
+    vals = np.asarray(field_values)
+    excluded = np.asarray(field_mask, dtype=bool)
+    n_vox = int(np.prod(grid_shape))
+    out = np.full(n_vox, fill_value, dtype="float32")
+    if gate_indices.shape[0] == 0:
+        return out.reshape(grid_shape)
+    drop = excluded[gate_indices]
+    w_eff = np.where(drop, 0.0, weights)
+    num = w_eff * np.where(drop, 0.0, vals[gate_indices])
+    lengths = np.diff(indptr)
+    rows = np.nonzero(lengths > 0)[0]
+    starts = indptr[:-1][rows]
+    num_sum = np.add.reduceat(num, starts)
+    den_sum = np.add.reduceat(w_eff, starts)
+    ok = den_sum > 0
+    out[rows[ok]] = num_sum[ok] / den_sum[ok]
+    return out.reshape(grid_shape)
+
+
+def csr_apply_f64(indptr, gate_indices, weights, field_values, field_mask, grid_shape,
+                  fill_value=np.nan) -> np.ndarray:
+    """Same contract as :func:`csr_apply` with float64 sums (float32 products kept): the yardstick used to
+    size the tolerance between the reference's float32 pairwise sums and the GPU's float64 accumulators."""
+    indptr = np.asarray(indptr, dtype=np.int64)
+    n_vox = int(np.prod(grid_shape))
+    out = np.full(n_vox, fill_value, dtype="float32")
+    if gate_indices.shape[0] == 0:
+        return out.reshape(grid_shape)
+    drop = np.asarray(field_mask, dtype=bool)[gate_indices]
+    w32 = np.where(drop, np.float32(0), np.asarray(weights, dtype=np.float32))
+    p32 = w32 * np.where(drop, np.float32(0), np.asarray(field_values, dtype=np.float32)[gate_indices])
+    row_of = np.repeat(np.arange(n_vox, dtype=np.int64), np.diff(indptr))
+    den = np.bincount(row_of, weights=w32.astype(np.float64), minlength=n_vox)
+    num = np.bincount(row_of, weights=p32.astype(np.float64), minlength=n_vox)
+    ok = den > 0
+    out[ok] = (num[ok] / den[ok]).astype(np.float32)
+    return out.reshape(grid_shape)
+
+
+def merge_masks(field_data, extra_masks: Sequence[np.ndarray] = ()) -> Tuple[np.ndarray, np.ndarray]:
+    """interpolate.py:59-64 -- OR the field's own mask with every filter's ``gate_excluded``."""
+    mask = np.ma.getmaskarray(field_data).copy()
+    for m in extra_masks:
+        mask |= np.asarray(m, dtype=bool)
+    return np.ma.getdata(field_data), mask
+
+
+# --------------------------------------------------------------------------------------------------
+# gate filters (src/radar_grid/filters.py:114-258) -- mask producers
+# --------------------------------------------------------------------------------------------------
+def gate_mask(op: str, data: np.ndarray, a: float = 0.0, b: float = 0.0) -> np.ndarray:
+    """Boolean ``True = excluded`` predicates of GateFilter: NaN compares False, so NaN gates are *not*
+    excluded by threshold filters (filters.py:134,157,182,207); ``invalid`` is NaN|Inf (filters.py:257)."""
+    d = np.asarray(data)
+    with np.errstate(invalid="ignore"):
+        if op == "below":
+            return d < a
+        if op == "above":
+            return d > a
+        if op == "between":
+            return (d > a) & (d < b)
+        if op == "outside":
+            return (d < a) | (d > b)
+        if op == "equal":
+            return np.abs(d - a) < b
+        if op == "invalid":
+            return np.isnan(d) | np.isinf(d)
+    raise ValueError(op)
+
+
+# --------------------------------------------------------------------------------------------------
+# products (src/radar_grid/products.py:317-580)
+# --------------------------------------------------------------------------------------------------
+def cappi_plan(z_limits, nz: int, altitude: float, interpolation: str = "linear"):
+    """Scalar control flow of ``constant_altitude_ppi`` (products.py:361-412).  Returns one of
+    ``("nan",)``, ``("level", k)`` or ``("lerp", k_lo, w_lo, w_hi)`` (weights are Python floats)."""
+    z_min, z_max = z_limits
+    zc = np.linspace(z_min, z_max, nz, dtype="float32")
+    if altitude < z_min or altitude > z_max:                      # products.py:370-372
+        return ("nan",)
+    if interpolation == "nearest":                                 # products.py:375-378
+        return ("level", int(np.argmin(np.abs(zc - altitude))))
+    if interpolation != "linear":
+        raise ValueError(f"Unknown interpolation method: {interpolation}")
+    hit = np.isclose(zc, altitude, rtol=1e-6)                      # products.py:382-386
+    if np.any(hit):
+        return ("level", int(np.where(hit)[0][0]))
+    z_step = (z_max - z_min) / (nz - 1) if nz > 1 else 1.0         # products.py:389
+    z_frac = (altitude - z_min) / z_step
+    k = int(np.floor(z_frac))
+    if k < 0:
+        return ("level", 0)
+    if k + 1 >= nz:
+        return ("level", nz - 1)
+    w_hi = z_frac - k
+    return ("lerp", k, 1.0 - w_hi, w_hi)
+
+
+def cappi(grid: np.ndarray, z_limits, altitude: float, interpolation: str = "linear") -> np.ndarray:
+    """CAPPI (products.py:317-415).  The lerp is ``w_lo*lo + w_hi*hi`` with weak Python-float weights,
+    i.e. float32 multiplies and a float32 add under NumPy >= 2; NaN in either level gives NaN."""
+    nz, ny, nx = grid.shape
+    plan = cappi_plan(z_limits, nz, altitude, interpolation)
+    if plan[0] == "nan":
+        return np.full((ny, nx), np.nan, dtype="float32")
+    if plan[0] == "level":
+        return grid[plan[1]]
+    _, k, w_lo, w_hi = plan
+    return (w_lo * grid[k] + w_hi * grid[k + 1]).astype("float32")
+
+
+def column_range(nz: int, z_min_idx=None, z_max_idx=None, z_min_alt=None, z_max_alt=None, z_limits=None):
+    """Index window of ``column_max|min|mean`` (products.py:462-485): altitude limits go through
+    ``searchsorted`` on the float64 linspace, then defaults and clipping."""
+    if z_min_alt is not None or z_max_alt is not None:
+        if z_limits is None:
+            raise ValueError("geometry is required when using altitude-based limits")
+        zc = np.linspace(z_limits[0], z_limits[1], nz)
+        if z_min_alt is not None:
+            z_min_idx = int(np.searchsorted(zc, z_min_alt))
+        if z_max_alt is not None:
+            z_max_idx = int(np.searchsorted(zc, z_max_alt, side="right")) - 1
+    if z_min_idx is None:
+        z_min_idx = 0
+    if z_max_idx is None:
+        z_max_idx = nz - 1
+    return max(0, z_min_idx), min(nz - 1, z_max_idx)
+
+
+def column_max(grid, lo: int, hi: int) -> np.ndarray:
+    """products.py:488-490 -- ``np.nanmax`` over levels ``lo..hi``; an all-NaN column stays NaN."""
+    with np.errstate(all="ignore"):
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            return np.nanmax(grid[lo:hi + 1], axis=0)
+
+
+def column_min(grid, lo: int, hi: int) -> np.ndarray:
+    """products.py:533-535 -- ``np.nanmin``."""
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        return np.nanmin(grid[lo:hi + 1], axis=0)
+
+
+def column_mean(grid, lo: int, hi: int) -> np.ndarray:
+    """products.py:578-580 -- ``np.nanmean``."""
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        return np.nanmean(grid[lo:hi + 1], axis=0)
+
+
+def column_argmax(grid, lo: int, hi: int) -> np.ndarray:
+    """Build-defined contract (the reference has no argmax): level index, *relative to the
+    full grid*, of the first level attaining the column's NaN-ignoring maximum (``np.nanargmax`` order),
+    ``-1`` for an all-NaN column.  int32."""
+    sl = grid[lo:hi + 1]
+    all_nan = np.all(np.isnan(sl), axis=0)
+    safe = np.where(np.isnan(sl), -np.inf, sl)
+    arg = np.argmax(safe, axis=0).astype(np.int32) + np.int32(lo)
+    arg[all_nan] = -1
+    return arg
+
+
+# --------------------------------------------------------------------------------------------------
+# antenna transform (PyART, not in /root/reference: parity unpinned)
+# --------------------------------------------------------------------------------------------------
+def antenna_to_cartesian(ranges_m, az_deg, el_deg):
+    """4/3-earth model as published for PyART's ``antenna_to_cartesian`` (arm-pyart >= 2.1.1, call sites
+    src/radar_grid/utils.py:35-37).  No reference test pins a gate coordinate: parity unpinned."""
+    r = np.asarray(ranges_m, dtype=np.float64)
+    az = np.asarray(az_deg, dtype=np.float64) * np.pi / 180.0
+    el = np.asarray(el_deg, dtype=np.float64) * np.pi / 180.0
+    big_r = EARTH_RADIUS * EFFECTIVE_RADIUS_FACTOR
+    z = (r ** 2 + big_r ** 2 + 2.0 * r * big_r * np.sin(el)) ** 0.5 - big_r
+    s = big_r * np.arcsin(r * np.cos(el) / (big_r + z))
+    return s * np.sin(az), s * np.cos(az), z

@@ -1,0 +1,74 @@
+"""Build recipe for libradargrid_hip.so (gfx950 only, in-tree so the .so travels with the snapshot).
+
+    python -m radar_processor_amd.build [--force]
+
+hipcc cross-compiles for gfx950 without a GPU.  The geometry translation unit is compiled with FP
+contraction disabled (it reproduces NumPy's unfused float64 arithmetic); everything else uses -O3 defaults.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from typing import List
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+LIB_PATH = os.path.join(CSRC, "libradargrid_hip.so")
+ARCH = "gfx950"
+
+# (source, extra flags)
+SOURCES = [
+    ("rg_core.hip", []),
+    ("rg_csr_apply.hip", []),
+    ("rg_products.hip", []),
+    ("rg_geometry.hip", ["-ffp-contract=off"]),
+    ("rg_roi_grid.hip", []),
+]
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found; libradargrid_hip.so cannot be built")
+    return exe
+
+
+def _stale(target: str, deps: List[str]) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    """Compile every HIP source for gfx950 and link the shared library. Returns its path."""
+    hipcc = _hipcc()
+    headers = [os.path.join(CSRC, "rg_common.hpp"), os.path.join(INCLUDE, "radargrid_hip.h")]
+    common = ["-std=c++17", "-O3", f"--offload-arch={ARCH}", "-fPIC",
+              f"-I{INCLUDE}", f"-I{CSRC}", "-Wall", "-Wno-unused-result"]
+    objs = []
+    for src, extra in SOURCES:
+        src_path = os.path.join(CSRC, src)
+        if not os.path.exists(src_path):
+            continue
+        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, [src_path] + headers):
+            cmd = [hipcc, *common, *extra, "-c", src_path, "-o", obj]
+            if verbose:
+                print("[build]", " ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+    if force or _stale(LIB_PATH, objs):
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB_PATH]
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB_PATH)

@@ -1,0 +1,338 @@
+// Geometry builder: gate -> voxel neighbour search + weights, on the GPU.
+// Replaces radar_grid/compute.py:18-103 (_process_single_level: per-level cKDTree + Python loop over
+// voxels) and the CSR merge of compute.py:232-272.
+//
+// THIS TRANSLATION UNIT IS COMPILED WITH -ffp-contract=off: membership `d2 < r2` and the weights are the
+// reference's float64 expressions evaluated operation by operation (compute.py:46-47,69-74,82-87); a fused
+// multiply-add would round differently from NumPy and could flip a rim gate.
+//
+// Search structure: gates that pass the toa test are bucketed into a uniform (x,y) cell grid that covers
+// the voxel grid grown by the largest ROI, then stably radix-sorted by cell id (rocPRIM).  All gates of
+// one cell row [cy][cx0..cx1] are therefore ONE contiguous run of 16-byte records, and the runs a voxel
+// has to test are a provable superset of its ROI ball: cell_coord() is monotone in the coordinate, so a
+// gate with x - r <= gx <= x + r lies in a cell between cell(x - r) and cell(x + r).
+//
+// Work mapping: one wavefront per voxel (kVoxPerWave consecutive voxels per wave, looped).  Everything
+// per-voxel is wave-uniform (scalar loads, SALU loop control); the 64 lanes test 64 candidate gates per
+// step with one coalesced dwordx4 load each; hits are compacted with ballot + mbcnt, so a row comes out
+// in (cell row, gate index) order -- deterministic, no atomics.
+#include <string.h>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
+
+#include "rg_common.hpp"
+
+namespace {
+
+constexpr int kVoxPerWave = 8;
+
+struct Cells {
+  double x0, y0, inv_cx, inv_cy, z_lo, z_hi;
+  int ncx, ncy;
+};
+
+inline Cells to_cells(const rg_cellgrid* c) {
+  Cells r;
+  r.x0 = c->x0; r.y0 = c->y0; r.inv_cx = c->inv_cx; r.inv_cy = c->inv_cy; r.z_lo = c->z_lo; r.z_hi = c->z_hi;
+  r.ncx = c->ncx; r.ncy = c->ncy;
+  return r;
+}
+
+__device__ __forceinline__ double cell_coord(double g, double origin, double inv) { return floor((g - origin) * inv); }
+
+__device__ __forceinline__ int cell_clamped(double g, double origin, double inv, int n) {
+  const double t = cell_coord(g, origin, inv);
+  return t < 0.0 ? 0 : (t >= (double)n ? n - 1 : (int)t);
+}
+
+// ---- binning ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(rg::kBlock) void bin_keys_kernel(const float* __restrict__ gx, const float* __restrict__ gy,
+                                                              const float* __restrict__ gz, long n, float radar_alt,
+                                                              float toa, Cells c, unsigned* __restrict__ keys,
+                                                              unsigned* __restrict__ vals) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  // compute.py:182 -- float32 subtraction (weak Python scalar under NumPy >= 2); compute.py:193 -- z_rel <= toa
+  const float z_rel = __fsub_rn(gz[i], radar_alt);
+  const double x = (double)gx[i], y = (double)gy[i], z = (double)z_rel;
+  const double tx = cell_coord(x, c.x0, c.inv_cx), ty = cell_coord(y, c.y0, c.inv_cy);
+  // NaN coordinates fail every comparison and are dropped
+  const bool keep = z_rel <= toa && z >= c.z_lo && z <= c.z_hi && tx >= 0.0 && tx < (double)c.ncx && ty >= 0.0 &&
+                    ty < (double)c.ncy;
+  keys[i] = keep ? (unsigned)((int)ty * c.ncx + (int)tx) : (unsigned)(c.ncx * c.ncy);
+  vals[i] = (unsigned)i;
+}
+
+// cell_start[c] = first sorted position whose key >= c, c = 0..n_cells (cell_start[n_cells] = #binned gates)
+__global__ __launch_bounds__(rg::kBlock) void cell_start_kernel(const unsigned* __restrict__ keys, long n,
+                                                                unsigned n_cells, int* __restrict__ cell_start) {
+  const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > n_cells) return;
+  long lo = 0, hi = n;
+  while (lo < hi) {
+    const long mid = (lo + hi) >> 1;
+    if (keys[mid] < c) lo = mid + 1; else hi = mid;
+  }
+  cell_start[c] = (int)lo;
+}
+
+__global__ __launch_bounds__(rg::kBlock) void gather_sorted_kernel(const unsigned* __restrict__ keys,
+                                                                   const unsigned* __restrict__ vals, long n,
+                                                                   unsigned n_cells, const float* __restrict__ gx,
+                                                                   const float* __restrict__ gy,
+                                                                   const float* __restrict__ gz, float radar_alt,
+                                                                   rg_gate4* __restrict__ sorted) {
+  const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n || keys[j] >= n_cells) return;
+  const unsigned g = vals[j];
+  rg_gate4 r;
+  r.x = gx[g];
+  r.y = gy[g];
+  r.z = __fsub_rn(gz[g], radar_alt);
+  r.index = (int)g;
+  sorted[j] = r;
+}
+
+// ---- ROI search ------------------------------------------------------------------------------------
+struct SearchArgs {
+  const rg_gate4* sorted;
+  const int* cell_start;
+  Cells c;
+  const float* xc;
+  const float* yc;
+  const float* zc;
+  int nz, ny, nx;
+  long n_vox;
+  double min_radius, beam_factor;
+};
+
+template <int W>
+__device__ __forceinline__ float roi_weight(double d2, double r2) {
+  if constexpr (W == RG_W_BARNES2) {
+    return (float)(exp(-d2 / (r2 / 4.0)) + 1e-5);  // compute.py:83
+  } else if constexpr (W == RG_W_CRESSMAN) {
+    return (float)((r2 - d2) / (r2 + d2));         // compute.py:85
+  } else {
+    return 1.0f;                                    // compute.py:87 ('nearest' = uniform mean)
+  }
+}
+
+constexpr int kCount = 0, kFill = 1;
+
+template <int MODE, int W>
+__global__ __launch_bounds__(rg::kBlock) void roi_kernel(SearchArgs a, int* __restrict__ counts,
+                                                         const long long* __restrict__ indptr, int* __restrict__ gidx,
+                                                         float* __restrict__ wts) {
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long wave = (long)blockIdx.x * (rg::kBlock / rg::kWave) + wv;
+  const long vbeg = wave * kVoxPerWave;
+  for (int t = 0; t < kVoxPerWave; ++t) {
+    const long v = vbeg + t;
+    if (v >= a.n_vox) break;  // wave-uniform
+    const int ix = (int)(v % a.nx);
+    const long q = v / a.nx;
+    const int iy = (int)(q % a.ny);
+    const int iz = (int)(q / a.ny);
+    const double x = (double)a.xc[ix], y = (double)a.yc[iy], z = (double)a.zc[iz];
+    const double dist = sqrt(x * x + y * y + z * z);               // compute.py:46
+    const double r = fmax(a.min_radius, dist * a.beam_factor);     // compute.py:47
+    const double r2 = r * r;                                       // compute.py:57
+    const int cx0 = __builtin_amdgcn_readfirstlane(cell_clamped(x - r, a.c.x0, a.c.inv_cx, a.c.ncx));
+    const int cx1 = __builtin_amdgcn_readfirstlane(cell_clamped(x + r, a.c.x0, a.c.inv_cx, a.c.ncx));
+    const int cy0 = __builtin_amdgcn_readfirstlane(cell_clamped(y - r, a.c.y0, a.c.inv_cy, a.c.ncy));
+    const int cy1 = __builtin_amdgcn_readfirstlane(cell_clamped(y + r, a.c.y0, a.c.inv_cy, a.c.ncy));
+    int count = 0;
+    long long base = 0;
+    if constexpr (MODE == kFill) base = indptr[v];
+    for (int cy = cy0; cy <= cy1; ++cy) {
+      const int s = a.cell_start[cy * a.c.ncx + cx0];
+      const int e = a.cell_start[cy * a.c.ncx + cx1 + 1];
+      for (int jb = s; jb < e; jb += 64) {
+        const int j = jb + lane;
+        bool hit = false;
+        double d2 = 0.0;
+        int gi = 0;
+        if (j < e) {
+          const rg_gate4 g = a.sorted[j];
+          const double dx = (double)g.x - x, dy = (double)g.y - y, dz = (double)g.z - z;  // compute.py:69-71
+          d2 = dx * dx + dy * dy + dz * dz;                                               // compute.py:72
+          hit = d2 < r2;                                                                  // compute.py:74
+          gi = g.index;
+        }
+        const unsigned long long m = __ballot(hit);
+        if constexpr (MODE == kFill) {
+          if (hit) {
+            const int pos = count + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                                    __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            gidx[base + pos] = gi;
+            wts[base + pos] = roi_weight<W>(d2, r2);
+          }
+        }
+        count += __popcll(m);
+      }
+    }
+    if constexpr (MODE == kCount) {
+      if (lane == 0) counts[v] = count;
+    }
+  }
+}
+
+struct WidenI32 {
+  __host__ __device__ long long operator()(int v) const { return (long long)v; }
+};
+
+inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+size_t sort_temp_bytes(size_t n, unsigned end_bit) {
+  size_t bytes = 0;
+  unsigned* nul = nullptr;
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, nul, nul, nul, nul, n, 0u, end_bit, (hipStream_t)0, false);
+  return bytes;
+}
+
+unsigned key_bits(unsigned n_cells) {
+  unsigned b = 1;
+  while (b < 32 && (1ull << b) <= n_cells) ++b;
+  return b;
+}
+
+int check_search_args(const char* fn, const rg_gate4* sorted, const int32_t* cell_start, const rg_cellgrid* cells,
+                      const float* xc, const float* yc, const float* zc, int nz, int ny, int nx) {
+  RG_REQUIRE(sorted && cell_start && cells && xc && yc && zc, RG_EINVAL, "%s: null pointer", fn);
+  RG_REQUIRE(nz >= 1 && ny >= 1 && nx >= 1, RG_EINVAL, "%s: bad grid shape (%d,%d,%d)", fn, nz, ny, nx);
+  RG_REQUIRE(cells->ncx >= 1 && cells->ncy >= 1 && (long)cells->ncx * cells->ncy < 0x7FFFFFFFL, RG_EINVAL,
+             "%s: bad cell grid %dx%d", fn, cells->ncx, cells->ncy);
+  RG_REQUIRE(rg::aligned16(sorted), RG_EALIGN, "%s: sorted_gates must be 16-byte aligned", fn);
+  return RG_OK;
+}
+
+SearchArgs make_args(const rg_gate4* sorted, const int32_t* cell_start, const rg_cellgrid* cells, const float* xc,
+                     const float* yc, const float* zc, int nz, int ny, int nx, double min_radius, double beam_factor) {
+  SearchArgs a;
+  a.sorted = sorted; a.cell_start = cell_start; a.c = to_cells(cells);
+  a.xc = xc; a.yc = yc; a.zc = zc; a.nz = nz; a.ny = ny; a.nx = nx;
+  a.n_vox = (long)nz * ny * nx;
+  a.min_radius = min_radius; a.beam_factor = beam_factor;
+  return a;
+}
+
+inline dim3 search_grid(long n_vox) {
+  const long waves = (n_vox + kVoxPerWave - 1) / kVoxPerWave;
+  return dim3((unsigned)((waves + 3) / 4));
+}
+
+}  // namespace
+
+extern "C" int64_t rg_geom_bin_workspace_bytes(int64_t n_gates, int32_t ncx, int32_t ncy) {
+  if (n_gates < 0 || ncx < 1 || ncy < 1) return RG_EINVAL;
+  const size_t n = (size_t)n_gates;
+  const size_t arr = round_up(n * sizeof(unsigned), 256);
+  return (int64_t)(4 * arr + round_up(sort_temp_bytes(n, key_bits((unsigned)ncx * (unsigned)ncy)), 256) + 256);
+}
+
+extern "C" int rg_geom_bin_gates_f32(const float* gate_x, const float* gate_y, const float* gate_z, int64_t n_gates,
+                                     float radar_altitude, float toa, const rg_cellgrid* cells_host,
+                                     rg_gate4* sorted_gates, int32_t* cell_start, void* workspace,
+                                     int64_t workspace_bytes, rg_stream_t stream) {
+  RG_REQUIRE(cells_host && cell_start, RG_EINVAL, "rg_geom_bin_gates_f32: null pointer");
+  RG_REQUIRE(n_gates >= 0 && n_gates <= 0x7FFFFFFFL, RG_EINVAL, "rg_geom_bin_gates_f32: n_gates out of range");
+  RG_REQUIRE(n_gates == 0 || (gate_x && gate_y && gate_z && sorted_gates && workspace), RG_EINVAL,
+             "rg_geom_bin_gates_f32: null pointer");
+  RG_REQUIRE(cells_host->ncx >= 1 && cells_host->ncy >= 1 && (long)cells_host->ncx * cells_host->ncy < 0x7FFFFFFFL,
+             RG_EINVAL, "rg_geom_bin_gates_f32: bad cell grid");
+  RG_REQUIRE(rg::aligned16(sorted_gates), RG_EALIGN, "rg_geom_bin_gates_f32: sorted_gates must be 16-byte aligned");
+  const int64_t need = rg_geom_bin_workspace_bytes(n_gates, cells_host->ncx, cells_host->ncy);
+  RG_REQUIRE(workspace_bytes >= need, RG_EWORKSPACE, "rg_geom_bin_gates_f32: workspace %lld < %lld bytes",
+             (long long)workspace_bytes, (long long)need);
+  hipStream_t s = (hipStream_t)stream;
+  const Cells c = to_cells(cells_host);
+  const unsigned n_cells = (unsigned)c.ncx * (unsigned)c.ncy;
+  const size_t n = (size_t)n_gates;
+  const size_t arr = round_up(n * sizeof(unsigned), 256);
+  char* base = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+  unsigned* keys_in = reinterpret_cast<unsigned*>(base);
+  unsigned* vals_in = reinterpret_cast<unsigned*>(base + arr);
+  unsigned* keys_out = reinterpret_cast<unsigned*>(base + 2 * arr);
+  unsigned* vals_out = reinterpret_cast<unsigned*>(base + 3 * arr);
+  void* temp = base + 4 * arr;
+  if (n > 0) {
+    const dim3 grid((unsigned)((n + rg::kBlock - 1) / rg::kBlock)), block(rg::kBlock);
+    hipLaunchKernelGGL(bin_keys_kernel, grid, block, 0, s, gate_x, gate_y, gate_z, (long)n, radar_altitude, toa, c,
+                       keys_in, vals_in);
+    const unsigned bits = key_bits(n_cells);
+    size_t temp_bytes = sort_temp_bytes(n, bits);
+    hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0u, bits, s, false);
+    RG_REQUIRE(e == hipSuccess, RG_ELAUNCH, "rg_geom_bin_gates_f32: radix sort: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(gather_sorted_kernel, grid, block, 0, s, keys_out, vals_out, (long)n, n_cells, gate_x, gate_y,
+                       gate_z, radar_altitude, sorted_gates);
+  }
+  hipLaunchKernelGGL(cell_start_kernel, dim3((n_cells + 1 + rg::kBlock - 1) / rg::kBlock), dim3(rg::kBlock), 0, s,
+                     keys_out, (long)n, n_cells, cell_start);
+  return rg::check_launch("rg_geom_bin_gates_f32");
+}
+
+extern "C" int rg_geom_count_f32(const rg_gate4* sorted_gates, const int32_t* cell_start, const rg_cellgrid* cells_host,
+                                 const float* xc, const float* yc, const float* zc, int32_t nz, int32_t ny, int32_t nx,
+                                 double min_radius, double beam_factor, int32_t* counts, rg_stream_t stream) {
+  const int rc = check_search_args("rg_geom_count_f32", sorted_gates, cell_start, cells_host, xc, yc, zc, nz, ny, nx);
+  if (rc != RG_OK) return rc;
+  RG_REQUIRE(counts, RG_EINVAL, "rg_geom_count_f32: null counts");
+  const SearchArgs a = make_args(sorted_gates, cell_start, cells_host, xc, yc, zc, nz, ny, nx, min_radius, beam_factor);
+  hipLaunchKernelGGL((roi_kernel<kCount, RG_W_NEAREST>), search_grid(a.n_vox), dim3(rg::kBlock), 0, (hipStream_t)stream, a,
+                     counts, (const long long*)nullptr, (int*)nullptr, (float*)nullptr);
+  return rg::check_launch("rg_geom_count_f32");
+}
+
+extern "C" int64_t rg_scan_workspace_bytes(int64_t n) {
+  if (n < 0) return RG_EINVAL;
+  size_t bytes = 0;
+  auto in = rocprim::make_transform_iterator((const int*)nullptr, WidenI32());
+  (void)rocprim::exclusive_scan(nullptr, bytes, in, (long long*)nullptr, 0ll, (size_t)n + 1, rocprim::plus<long long>(),
+                                (hipStream_t)0, false);
+  return (int64_t)round_up(bytes, 256) + 256;
+}
+
+extern "C" int rg_scan_counts_i64(const int32_t* counts, int64_t n, int64_t* indptr, void* workspace,
+                                  int64_t workspace_bytes, rg_stream_t stream) {
+  // counts must hold n+1 readable entries (the last one is ignored by the exclusive scan's output[n] = total)
+  RG_REQUIRE(counts && indptr && workspace, RG_EINVAL, "rg_scan_counts_i64: null pointer");
+  RG_REQUIRE(n >= 0, RG_EINVAL, "rg_scan_counts_i64: negative size");
+  RG_REQUIRE(workspace_bytes >= rg_scan_workspace_bytes(n), RG_EWORKSPACE, "rg_scan_counts_i64: workspace too small");
+  char* base = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+  size_t bytes = (size_t)workspace_bytes - (size_t)(base - reinterpret_cast<char*>(workspace));
+  auto in = rocprim::make_transform_iterator(counts, WidenI32());
+  hipError_t e = rocprim::exclusive_scan(base, bytes, in, reinterpret_cast<long long*>(indptr), 0ll, (size_t)n + 1,
+                                         rocprim::plus<long long>(), (hipStream_t)stream, false);
+  RG_REQUIRE(e == hipSuccess, RG_ELAUNCH, "rg_scan_counts_i64: %s", hipGetErrorString(e));
+  return RG_OK;
+}
+
+extern "C" int rg_geom_fill_f32(const rg_gate4* sorted_gates, const int32_t* cell_start, const rg_cellgrid* cells_host,
+                                const float* xc, const float* yc, const float* zc, int32_t nz, int32_t ny, int32_t nx,
+                                double min_radius, double beam_factor, int32_t weighting, const int64_t* indptr,
+                                int32_t* gate_idx, float* weights, rg_stream_t stream) {
+  const int rc = check_search_args("rg_geom_fill_f32", sorted_gates, cell_start, cells_host, xc, yc, zc, nz, ny, nx);
+  if (rc != RG_OK) return rc;
+  RG_REQUIRE(indptr && gate_idx && weights, RG_EINVAL, "rg_geom_fill_f32: null pointer");
+  RG_REQUIRE(weighting >= RG_W_BARNES2 && weighting <= RG_W_NEAREST, RG_EINVAL, "rg_geom_fill_f32: unknown weighting %d",
+             weighting);
+  const SearchArgs a = make_args(sorted_gates, cell_start, cells_host, xc, yc, zc, nz, ny, nx, min_radius, beam_factor);
+  const dim3 grid = search_grid(a.n_vox), block(rg::kBlock);
+  hipStream_t s = (hipStream_t)stream;
+  const long long* ip = reinterpret_cast<const long long*>(indptr);
+  switch (weighting) {
+    case RG_W_BARNES2:
+      hipLaunchKernelGGL((roi_kernel<kFill, RG_W_BARNES2>), grid, block, 0, s, a, (int*)nullptr, ip, gate_idx, weights);
+      break;
+    case RG_W_CRESSMAN:
+      hipLaunchKernelGGL((roi_kernel<kFill, RG_W_CRESSMAN>), grid, block, 0, s, a, (int*)nullptr, ip, gate_idx, weights);
+      break;
+    default:
+      hipLaunchKernelGGL((roi_kernel<kFill, RG_W_NEAREST>), grid, block, 0, s, a, (int*)nullptr, ip, gate_idx, weights);
+      break;
+  }
+  return rg::check_launch("rg_geom_fill_f32");
+}

@@ -1,0 +1,225 @@
+"""CSR geometry container and its ``.npz`` persistence -- host-side mirror of
+``radar_grid/geometry.py`` (``GridGeometry`` :14-91, ``save_geometry`` :94-118, ``load_geometry`` :121-150).
+
+Same constructor arguments, attributes, helper methods, ``__repr__`` text and on-disk keys as the reference,
+so geometry files are interchangeable.  What is new is where the arrays live: the CSR can be *device
+resident* (built by the GPU builder, or uploaded once and cached), because at the sizes MI355X is meant for
+(tens of GB of pairs, int64 row pointers) a host copy is neither needed nor wanted.  Host views
+(``.indptr`` / ``.gate_indices`` / ``.weights``) are materialised lazily on first access.
+"""
+from __future__ import annotations
+
+import logging
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _native
+
+logger = logging.getLogger("radar_grid.geometry")  # same logger name as the reference (docs/LOGGING.md:128-141)
+
+_INT32_MAX = np.iinfo(np.int32).max
+
+
+class DeviceCSR:
+    """CSR arrays resident in HBM (torch tensors used purely as allocations)."""
+
+    __slots__ = ("indptr", "gate_indices", "weights", "n_vox", "n_pairs", "max_gate", "is_i64")
+
+    def __init__(self, indptr, gate_indices, weights, max_gate: int):
+        self.indptr = indptr
+        self.gate_indices = gate_indices
+        self.weights = weights
+        self.n_vox = int(indptr.shape[0]) - 1
+        self.n_pairs = int(gate_indices.shape[0])
+        self.max_gate = int(max_gate)   # largest gate index referenced (-1 when there are no pairs)
+        self.is_i64 = indptr.dtype == _native.torch_mod().int64
+
+    def nbytes(self) -> int:
+        return sum(int(t.numel()) * t.element_size() for t in (self.indptr, self.gate_indices, self.weights))
+
+
+class GridGeometry:
+    """Precomputed gate -> voxel mapping in CSR form (``radar_grid/geometry.py:14-52``).
+
+    Row ``v = (iz*ny + iy)*nx + ix`` owns ``gate_indices[indptr[v]:indptr[v+1]]`` and the matching
+    ``weights``.  ``indptr`` is int32 like the reference's whenever the pair count fits, int64 otherwise
+    (the reference overflows there).
+    """
+
+    def __init__(self, grid_shape: Tuple[int, int, int], grid_limits, indptr, gate_indices, weights,
+                 toa: float, radar_altitude: float = 0.0):
+        self.grid_shape = grid_shape
+        self.grid_limits = grid_limits
+        self.toa = toa
+        self.radar_altitude = radar_altitude
+        self._indptr = indptr
+        self._gate_indices = gate_indices
+        self._weights = weights
+        self._dev: Optional[DeviceCSR] = None
+
+    # ---- construction from device-resident arrays (GPU builder) -----------------------------------
+    @classmethod
+    def from_device(cls, grid_shape, grid_limits, csr: DeviceCSR, toa: float, radar_altitude: float = 0.0):
+        g = cls(grid_shape, grid_limits, None, None, None, toa, radar_altitude)
+        g._dev = csr
+        return g
+
+    # ---- host views (lazy) -----------------------------------------------------------------------
+    def _host(self, name: str):
+        arr = getattr(self, "_" + name)
+        if arr is None:
+            if self._dev is None:
+                raise AttributeError(f"GridGeometry has no {name}")
+            logger.debug("copying %s to the host", name)
+            arr = getattr(self._dev, name).cpu().numpy()
+            setattr(self, "_" + name, arr)
+        return arr
+
+    @property
+    def indptr(self) -> np.ndarray:
+        return self._host("indptr")
+
+    @indptr.setter
+    def indptr(self, value):
+        self._indptr, self._dev = value, None
+
+    @property
+    def gate_indices(self) -> np.ndarray:
+        return self._host("gate_indices")
+
+    @gate_indices.setter
+    def gate_indices(self, value):
+        self._gate_indices, self._dev = value, None
+
+    @property
+    def weights(self) -> np.ndarray:
+        return self._host("weights")
+
+    @weights.setter
+    def weights(self, value):
+        self._weights, self._dev = value, None
+
+    @property
+    def is_device_resident(self) -> bool:
+        return self._dev is not None
+
+    # ---- reference helper methods (geometry.py:54-91) --------------------------------------------
+    def memory_usage_mb(self) -> float:
+        if self._indptr is None and self._dev is not None:
+            return self._dev.nbytes() / 1e6
+        return (self.indptr.nbytes + self.gate_indices.nbytes + self.weights.nbytes) / 1e6
+
+    def n_grid_points(self) -> int:
+        return int(np.prod(self.grid_shape))
+
+    def n_pairs(self) -> int:
+        if self._gate_indices is None and self._dev is not None:
+            return self._dev.n_pairs
+        return len(self.gate_indices)
+
+    def avg_neighbors(self) -> float:
+        return self.n_pairs() / self.n_grid_points()
+
+    def z_levels(self) -> np.ndarray:
+        nz = self.grid_shape[0]
+        z_min, z_max = self.grid_limits[0]
+        return np.linspace(z_min, z_max, nz)
+
+    def z_levels_absolute(self) -> np.ndarray:
+        return self.z_levels() + self.radar_altitude
+
+    def __repr__(self) -> str:
+        return (
+            "GridGeometry(\n"
+            f"  grid_shape={self.grid_shape},\n"
+            f"  grid_limits={self.grid_limits},\n"
+            f"  toa={self.toa}m,\n"
+            f"  radar_altitude={self.radar_altitude}m,\n"
+            f"  n_pairs={self.n_pairs():,},\n"
+            f"  avg_neighbors={self.avg_neighbors():.1f},\n"
+            f"  memory={self.memory_usage_mb():.1f} MB\n"
+            ")"
+        )
+
+    def __eq__(self, other):  # the reference is a dataclass: field-wise equality
+        if not isinstance(other, GridGeometry):
+            return NotImplemented
+        return (tuple(self.grid_shape) == tuple(other.grid_shape) and self.grid_limits == other.grid_limits
+                and self.toa == other.toa and self.radar_altitude == other.radar_altitude
+                and np.array_equal(self.indptr, other.indptr)
+                and np.array_equal(self.gate_indices, other.gate_indices)
+                and np.array_equal(self.weights, other.weights))
+
+    __hash__ = None
+
+    # ---- device residency -----------------------------------------------------------------------
+    def device_csr(self, device=None) -> DeviceCSR:
+        """CSR in HBM: uploaded (and validated) once, then cached on the object."""
+        dev = _native.device() if device is None else device
+        if self._dev is not None and self._dev.indptr.device == dev:
+            return self._dev
+        torch = _native.torch_mod()
+        if self._dev is not None:   # resident on another GPU: replicate device-to-device
+            src = self._dev
+            self._dev = DeviceCSR(src.indptr.to(dev), src.gate_indices.to(dev), src.weights.to(dev), src.max_gate)
+            return self._dev
+        indptr = np.ascontiguousarray(self._indptr)
+        gidx = np.ascontiguousarray(self._gate_indices)
+        wts = np.ascontiguousarray(self._weights)
+        n_vox = self.n_grid_points()
+        if indptr.ndim != 1 or indptr.shape[0] != n_vox + 1:
+            raise ValueError(f"indptr has {indptr.shape[0]} entries, expected {n_vox + 1} for grid {self.grid_shape}")
+        if not np.issubdtype(indptr.dtype, np.integer):
+            raise ValueError("indptr must be an integer array")
+        if gidx.shape[0] != wts.shape[0]:
+            raise ValueError("gate_indices and weights differ in length")
+        if indptr.shape[0] and (indptr[0] != 0 or indptr[-1] != gidx.shape[0] or np.any(np.diff(indptr) < 0)):
+            raise ValueError("indptr must start at 0, end at len(gate_indices) and be non-decreasing")
+        if gidx.shape[0] and gidx.min() < 0:
+            raise ValueError("negative gate indices are not supported")
+        ip_dtype = np.int32 if gidx.shape[0] <= _INT32_MAX else np.int64
+        max_gate = int(gidx.max()) if gidx.shape[0] else -1
+        self._dev = DeviceCSR(
+            torch.from_numpy(indptr.astype(ip_dtype, copy=False)).to(dev),
+            torch.from_numpy(gidx.astype(np.int32, copy=False)).to(dev),
+            torch.from_numpy(wts.astype(np.float32, copy=False)).to(dev),
+            max_gate)
+        logger.info(f"Geometry resident on {dev}: {self._dev.nbytes() / 1e6:.1f} MB")
+        return self._dev
+
+
+def save_geometry(geometry: GridGeometry, filepath: str) -> None:
+    """Write the nine-key ``.npz`` of ``radar_grid/geometry.py:105-116`` (deflate-compressed)."""
+    np.savez_compressed(
+        filepath,
+        grid_shape=np.array(geometry.grid_shape),
+        grid_limits_z=np.array(geometry.grid_limits[0]),
+        grid_limits_y=np.array(geometry.grid_limits[1]),
+        grid_limits_x=np.array(geometry.grid_limits[2]),
+        indptr=geometry.indptr,
+        gate_indices=geometry.gate_indices,
+        weights=geometry.weights,
+        toa=np.array([geometry.toa]),
+        radar_altitude=np.array([geometry.radar_altitude]),
+    )
+    file_size_mb = os.path.getsize(filepath) / 1e6
+    logger.info(f"Saved geometry to {filepath} ({file_size_mb:.1f} MB on disk)")
+
+
+def load_geometry(filepath: str) -> GridGeometry:
+    """Read a geometry ``.npz``; files without ``toa`` / ``radar_altitude`` default to ``inf`` / ``0.0``
+    (``radar_grid/geometry.py:146-147``)."""
+    with np.load(filepath) as data:
+        geometry = GridGeometry(
+            grid_shape=tuple(data["grid_shape"]),
+            grid_limits=(tuple(data["grid_limits_z"]), tuple(data["grid_limits_y"]), tuple(data["grid_limits_x"])),
+            indptr=data["indptr"],
+            gate_indices=data["gate_indices"],
+            weights=data["weights"],
+            toa=float(data["toa"][0]) if "toa" in data else np.inf,
+            radar_altitude=float(data["radar_altitude"][0]) if "radar_altitude" in data else 0.0,
+        )
+    logger.info(f"Loaded geometry: {geometry.memory_usage_mb():.1f} MB in memory, toa={geometry.toa}m")
+    return geometry

@@ -1,0 +1,83 @@
+"""Shared test plumbing.
+
+Markers: ``gpu`` = needs a real MI355X (run by the driver with ``-m gpu``); everything else must pass on a
+CPU-only box.  Only tests (and bench.py's cpu_baseline leg / smoke()) may import ``oracle``.
+"""
+import functools
+import glob
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(REPO, "tests", "golden")
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X GPU (HIP kernels through the C ABI)")
+    config.addinivalue_line("markers", "slow: longer CPU-side oracle checks")
+
+
+def load_golden(name):
+    """Load one fixture: returns (meta dict, {array name: ndarray})."""
+    path = os.path.join(GOLDEN, name if name.endswith(".npz") else name + ".npz")
+    with np.load(path) as z:
+        arrays = {k: z[k] for k in z.files if k != "meta"}
+        meta = json.loads(bytes(z["meta"]).decode())
+    return meta, arrays
+
+
+def golden_names(prefix):
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, prefix + "*.npz")))
+
+
+@functools.lru_cache(maxsize=4)
+def golden_volume(n_elev, n_az, n_gates, seed, fields, flatten_z=False):
+    """Regenerate the synthetic volume a fixture was computed from (digest-checked by the caller)."""
+    from radar_processor_amd import synthetic
+    vol = synthetic.make_volume(n_elev=n_elev, n_az=n_az, n_gates=n_gates, seed=seed, fields=fields)
+    if flatten_z:
+        vol.gate_z = np.zeros_like(vol.gate_z)
+    return vol
+
+
+def volume_for(meta):
+    v = meta["volume"]
+    vol = golden_volume(v["n_elev"], v["n_az"], v["n_gates"], v["seed"], tuple(meta["fields"]),
+                        bool(v.get("flatten_z", False)))
+    assert vol.digest() == meta["digest"], "synthetic generator drifted from the one the fixture was made with"
+    return vol
+
+
+def builder_kwargs(meta):
+    return dict(radar_altitude=meta.get("radar_altitude", 0.0), min_radius=meta.get("min_radius", 250.0),
+                beam_factor=meta.get("beam_factor", 0.01746), weighting=meta["weighting"], toa=meta["toa"])
+
+
+def grid_spec(meta):
+    shape = tuple(meta["grid_shape"])
+    limits = tuple(tuple(float(x) for x in lim) for lim in meta["grid_limits"])
+    return shape, limits
+
+
+def reference_indices(name, meta, arrays):
+    """Non-barnes2 G3 fixtures share gate_indices with their barnes2 sibling (same neighbour sets)."""
+    if "gate_indices" in arrays:
+        return arrays["gate_indices"]
+    sibling = name.rsplit("_", 1)[0] + "_barnes2"
+    _, sib = load_golden(sibling)
+    return sib["gate_indices"]
+
+
+@pytest.fixture(scope="session")
+def has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False

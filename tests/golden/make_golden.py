@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE's own modules.
+
+Runs only in the build container (where /root/reference is mounted); the GPU box and the test-suite
+only ever read the .npz files this script wrote.  The reference package's ``__init__`` eagerly imports
+rasterio (absent), so the hot-path submodules are imported individually under a stub parent package
+(SURVEY.md §8(c)).  Nothing from the reference is copied: fixtures hold inputs' digests, kwargs and the
+reference's *outputs*.
+
+    python tests/golden/make_golden.py [--only g3 ...]
+
+Inputs are regenerated from seeds by ``radar_processor_amd.synthetic`` at test time; each fixture stores
+the sha256 digest of the volume it was computed from so generator drift is detected, plus the NumPy /
+SciPy versions (the reference's intermediates are float32 only under NumPy >= 2).
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import tempfile
+import time
+import types
+import warnings
+
+import numpy as np
+import scipy
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF_SRC = "/root/reference/src/radar_grid"
+sys.path.insert(0, REPO)
+sys.dont_write_bytecode = True
+
+
+def load_reference():
+    if not os.path.isdir(REF_SRC):
+        raise SystemExit("reference not mounted; golden vectors can only be regenerated in the build container")
+    pkg = types.ModuleType("radar_grid")
+    pkg.__path__ = [REF_SRC]
+    sys.modules["radar_grid"] = pkg
+    mods = {}
+    for name in ("geometry", "filters", "interpolate", "products", "compute", "utils"):
+        mods[name] = importlib.import_module("radar_grid." + name)
+    return types.SimpleNamespace(**mods)
+
+
+def window_limits(center_xy, shape, spacing_xy, z_limits):
+    nz, ny, nx = shape
+    cx, cy = center_xy
+    hx = 0.5 * (nx - 1) * spacing_xy
+    hy = 0.5 * (ny - 1) * spacing_xy
+    return (tuple(float(v) for v in z_limits), (cy - hy, cy + hy), (cx - hx, cx + hx))
+
+
+def meta_blob(**kw):
+    kw.update(numpy=np.__version__, scipy=scipy.__version__, generated=time.strftime("%Y-%m-%d"))
+    return np.frombuffer(json.dumps(kw, sort_keys=True).encode(), dtype=np.uint8)
+
+
+def run_window(ref, vol, shape, limits, weighting, radar_altitude=0.0, toa=17000.0, n_workers=4,
+               fields=("DBZH",), qc=None, extra_fill=None, min_radius=250.0, beam_factor=0.01746):
+    """Reference builder + apply on one window; returns dict of arrays for the fixture."""
+    with tempfile.TemporaryDirectory() as tmp:
+        geom = ref.compute.compute_grid_geometry(
+            vol.gate_x, vol.gate_y, vol.gate_z, shape, limits, tmp, radar_altitude=radar_altitude,
+            min_radius=min_radius, beam_factor=beam_factor, weighting=weighting, toa=toa, n_workers=n_workers)
+    out = dict(indptr=geom.indptr, gate_indices=geom.gate_indices, weights=geom.weights)
+    radar = vol.as_radar()
+    gf = None
+    if qc is not None:
+        gf = ref.filters.GateFilter(radar)
+        gf.exclude_below(qc[0], qc[1])
+        out["qc_excluded_count"] = np.array([int(gf.n_excluded())])
+    for name in fields:
+        fdata = ref.utils.get_field_data(radar, name)
+        # the reference needs a full-array mask
+        fdata = np.ma.array(np.ma.getdata(fdata), mask=np.ma.getmaskarray(fdata))
+        out[f"grid_{name}"] = ref.interpolate.apply_geometry(geom, fdata)
+        if gf is not None:
+            out[f"grid_{name}_qc"] = ref.interpolate.apply_geometry(geom, fdata, additional_filters=[gf])
+        if extra_fill is not None:
+            out[f"grid_{name}_fill"] = ref.interpolate.apply_geometry(geom, fdata, fill_value=extra_fill)
+    return geom, out
+
+
+def products_block(ref, grid, geom, prefix, out):
+    """CAPPI / column products of the reference on one gridded field."""
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        P = ref.products
+        out[f"{prefix}_cappi4000_linear"] = np.array(P.constant_altitude_ppi(grid, geom, 4000.0, "linear"))
+        out[f"{prefix}_cappi4000_nearest"] = np.array(P.constant_altitude_ppi(grid, geom, 4000.0, "nearest"))
+        out[f"{prefix}_cappi2500_linear"] = np.array(P.constant_altitude_ppi(grid, geom, 2500.0, "linear"))
+        out[f"{prefix}_cappi_above"] = np.array(P.constant_altitude_ppi(grid, geom, 99000.0, "linear"))
+        out[f"{prefix}_colmax"] = P.column_max(grid)
+        out[f"{prefix}_colmax_alt"] = P.column_max(grid, z_min_alt=1000, z_max_alt=8000, geometry=geom)
+        out[f"{prefix}_colmax_idx"] = P.column_max(grid, z_min_idx=2, z_max_idx=6)
+        out[f"{prefix}_colmin"] = P.column_min(grid)
+        out[f"{prefix}_colmean"] = P.column_mean(grid)
+        out[f"{prefix}_colmean_alt"] = P.column_mean(grid, z_min_alt=1000, z_max_alt=8000, geometry=geom)
+
+
+def gen_g2(ref, synth):
+    """C1: single PPI sweep 360x500 flattened to z=0, 2-D grid windows (1,48,48) at three ranges."""
+    vol = synth.make_volume(n_elev=1, n_az=360, n_gates=500, seed=1, fields=("DBZH",))
+    vol.gate_z = np.zeros_like(vol.gate_z)
+    for tag, centre in (("near", (6e3, -4e3)), ("mid", (70e3, 55e3)), ("far", (-150e3, 160e3))):
+        shape = (1, 48, 48)
+        limits = window_limits(centre, shape, 960.0, (0.0, 0.0))
+        geom, out = run_window(ref, vol, shape, limits, "barnes2", n_workers=1, extra_fill=-9999.0)
+        out["meta"] = meta_blob(case="G2", volume=dict(n_elev=1, n_az=360, n_gates=500, seed=1, flatten_z=True),
+                                digest=vol.digest(), grid_shape=shape, grid_limits=limits, weighting="barnes2",
+                                toa=17000.0, radar_altitude=0.0, fields=["DBZH"])
+        np.savez_compressed(os.path.join(HERE, f"g2_c1_{tag}.npz"), **out)
+        print("g2", tag, geom)
+
+
+def gen_g3(ref, synth):
+    """C2 volume (12x360x1000), windows (20,12,12) at true 480 m spacing, z 0..15 km."""
+    fields = ("DBZH", "ZDR", "RHOHV")
+    vol = synth.make_volume(n_elev=12, n_az=360, n_gates=1000, seed=0, fields=fields)
+    shape = (20, 12, 12)
+    cases = [
+        ("r010", (7.1e3, 7.3e3), ("barnes2", "cressman", "nearest")),
+        ("r060", (-42e3, 43e3), ("barnes2",)),
+        ("r150", (106e3, -106e3), ("barnes2", "cressman")),
+        ("r235", (-166e3, -166.4e3), ("barnes2",)),
+        ("corner", (237e3, 237e3), ("barnes2",)),
+    ]
+    for tag, centre, weightings in cases:
+        limits = window_limits(centre, shape, 480.0, (0.0, 15000.0))
+        for wname in weightings:
+            geom, out = run_window(ref, vol, shape, limits, wname, fields=fields, qc=("RHOHV", 0.8),
+                                   extra_fill=-9999.0 if wname == "barnes2" else None)
+            if wname == "barnes2":
+                products_block(ref, out["grid_DBZH"], geom, "DBZH", out)
+            if wname != "barnes2":
+                # identical neighbour sets and KD-tree order: keep only the weights
+                del out["gate_indices"]
+            out["meta"] = meta_blob(case="G3", volume=dict(n_elev=12, n_az=360, n_gates=1000, seed=0),
+                                    digest=vol.digest(), grid_shape=shape, grid_limits=limits, weighting=wname,
+                                    toa=17000.0, radar_altitude=0.0, fields=list(fields), qc=["RHOHV", 0.8])
+            np.savez_compressed(os.path.join(HERE, f"g3_c2_{tag}_{wname}.npz"), **out)
+            print("g3", tag, wname, geom)
+
+
+def gen_g4(ref, synth):
+    """C4 volume (14x720x2000, 120 m gates), windows (40,6,6) at 240 m spacing."""
+    vol = synth.make_volume(n_elev=14, n_az=720, n_gates=2000, seed=4, fields=("DBZH",))
+    shape = (40, 6, 6)
+    for tag, centre in (("r030", (21e3, -21.5e3)), ("r180", (-127e3, 128e3))):
+        limits = window_limits(centre, shape, 240.0, (0.0, 15000.0))
+        geom, out = run_window(ref, vol, shape, limits, "barnes2", n_workers=4)
+        out["meta"] = meta_blob(case="G4", volume=dict(n_elev=14, n_az=720, n_gates=2000, seed=4),
+                                digest=vol.digest(), grid_shape=shape, grid_limits=limits, weighting="barnes2",
+                                toa=17000.0, radar_altitude=0.0, fields=["DBZH"])
+        np.savez_compressed(os.path.join(HERE, f"g4_c4_{tag}.npz"), **out)
+        print("g4", tag, geom)
+
+
+def gen_g5(ref, synth):
+    """Products on a dense synthetic 3-D grid, incl. the exact-level CAPPI case (z 0..19 km, nz=20)."""
+    rng = np.random.default_rng(55)
+    grid = (rng.normal(15.0, 18.0, size=(20, 40, 56))).astype(np.float32)
+    grid[rng.random(grid.shape) < 0.25] = np.nan
+    grid[:, :6, :7] = np.nan                       # all-NaN columns
+    grid[3:9, 10:14, 20:30] = np.float32(41.5)     # ties for the argmax contract
+    grid[5, 30:34, 40:44] = np.float32(-0.0)
+    for tag, zlim in (("z15", (0.0, 15000.0)), ("z19", (0.0, 19000.0))):
+        geom = ref.geometry.GridGeometry(grid_shape=grid.shape, grid_limits=(zlim, (-1e4, 1e4), (-1.4e4, 1.4e4)),
+                                         indptr=np.zeros(grid.size + 1, dtype=np.int32),
+                                         gate_indices=np.zeros(0, dtype=np.int32),
+                                         weights=np.zeros(0, dtype=np.float32), toa=17000.0)
+        out = dict(grid=grid)
+        products_block(ref, grid, geom, "P", out)
+        out["meta"] = meta_blob(case="G5", grid_shape=grid.shape, z_limits=zlim)
+        np.savez_compressed(os.path.join(HERE, f"g5_products_{tag}.npz"), **out)
+        print("g5", tag)
+
+
+def gen_g6(ref, synth):
+    """radar_altitude != 0 pins the compute.py:182 subtraction and the toa cut; low toa drops sweeps."""
+    vol = synth.make_volume(n_elev=12, n_az=360, n_gates=1000, seed=6, fields=("DBZH",))
+    shape = (20, 10, 10)
+    limits = window_limits((-61e3, 88e3), shape, 480.0, (0.0, 15000.0))
+    geom, out = run_window(ref, vol, shape, limits, "barnes2", radar_altitude=438.5, toa=9000.0, n_workers=4,
+                           min_radius=400.0, beam_factor=0.02)
+    out["meta"] = meta_blob(case="G6", volume=dict(n_elev=12, n_az=360, n_gates=1000, seed=6),
+                            digest=vol.digest(), grid_shape=shape, grid_limits=limits, weighting="barnes2",
+                            toa=9000.0, radar_altitude=438.5, min_radius=400.0, beam_factor=0.02, fields=["DBZH"])
+    np.savez_compressed(os.path.join(HERE, "g6_altitude.npz"), **out)
+    print("g6", geom)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*", default=None)
+    args = ap.parse_args()
+    ref = load_reference()
+    from radar_processor_amd import synthetic as synth
+    gens = dict(g2=gen_g2, g3=gen_g3, g4=gen_g4, g5=gen_g5, g6=gen_g6)
+    for name, fn in gens.items():
+        if args.only and name not in args.only:
+            continue
+        t0 = time.time()
+        fn(ref, synth)
+        print(f"[{name}] {time.time() - t0:.1f}s", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,213 @@
+"""Pin the CPU oracle (oracle/radar_grid_oracle.py) before anything trusts it:
+
+ 1. the literal known answers of the reference's own tests
+    (/root/reference/tests/test_radar_grid_interpolate.py, test_radar_grid_products.py), and
+ 2. the golden vectors produced by running the reference's modules (tests/golden/make_golden.py).
+
+CPU only; no HIP code is touched here.
+"""
+import numpy as np
+import pytest
+
+from conftest import (builder_kwargs, golden_names, grid_spec, load_golden, reference_indices, volume_for)
+from oracle import radar_grid_oracle as oracle
+
+
+def _apply(indptr, idx, w, values, mask=None, shape=(1, 1, 1), fill=np.nan):
+    values = np.asarray(values, dtype=np.float32)
+    if mask is None:
+        mask = ~np.isfinite(values)          # what np.ma.masked_invalid does in the reference's tests
+    return oracle.csr_apply(np.asarray(indptr), np.asarray(idx, dtype=np.int32), np.asarray(w, dtype=np.float32),
+                            values, mask, shape, fill)
+
+
+# ------------------------------------------------------------------------------------------------
+# 1. reference unit-test known answers
+# ------------------------------------------------------------------------------------------------
+class TestReferenceKnownAnswers:
+    def test_weighted_average_17(self):          # test_radar_grid_interpolate.py:75-93
+        out = _apply([0, 2], [0, 1], [0.3, 0.7], [10.0, 20.0])
+        np.testing.assert_almost_equal(out[0, 0, 0], 17.0, decimal=5)
+
+    def test_single_point_21(self):              # :236-254
+        out = _apply([0, 3], [0, 1, 2], [0.2, 0.5, 0.3], [10.0, 20.0, 30.0])
+        np.testing.assert_almost_equal(out[0, 0, 0], 21.0, decimal=5)
+
+    def test_mixed_valid_invalid_20(self):       # :256-277
+        out = _apply([0, 3], [0, 1, 2], [0.3, 0.4, 0.3], [10.0, np.nan, 30.0])
+        np.testing.assert_almost_equal(out[0, 0, 0], 20.0, decimal=5)
+
+    def test_inf_excluded(self):                 # :283-299
+        out = _apply([0, 3], [0, 1, 2], [0.3, 0.4, 0.3], [10.0, np.inf, 30.0])
+        assert np.isfinite(out[0, 0, 0])
+
+    def test_negative_inf_excluded_10(self):     # :301-317
+        out = _apply([0, 2], [0, 1], [0.5, 0.5], [10.0, -np.inf])
+        np.testing.assert_almost_equal(out[0, 0, 0], 10.0, decimal=5)
+
+    def test_fill_value_on_empty_row(self):      # :116-132
+        out = _apply([0, 0], [], [], [10.0], fill=-9999.0)
+        assert out[0, 0, 0] == -9999.0
+
+    def test_all_masked_is_nan(self):            # :134-153
+        out = _apply([0, 2], [0, 1], [0.5, 0.5], [10.0, 20.0], mask=np.array([True, True]))
+        assert np.isnan(out[0, 0, 0])
+
+    def test_empty_geometry_all_fill(self):      # :218-234
+        out = _apply(np.zeros(9, dtype=np.int32), [], [], [10.0], shape=(2, 2, 2))
+        assert out.shape == (2, 2, 2) and np.all(np.isnan(out))
+
+    def test_nan_gates_first_voxel(self):        # :50-59
+        vals = np.ones(16, dtype=np.float32) * 10.0
+        vals[0:4] = np.nan
+        out = _apply(np.arange(0, 17, 2), np.arange(16), np.ones(16), vals, shape=(2, 2, 2))
+        assert out.dtype == np.float32 and np.isnan(out.ravel()[0]) and out.ravel()[2] == 10.0
+
+    def test_column_known_answers(self):         # test_radar_grid_products.py:284-357
+        data = np.zeros((10, 50, 50), dtype=np.float32)
+        for z in range(10):
+            data[z] = z * 10.0
+        data[:, 0:5, 0:5] = np.nan
+        cmax, cmin, cmean = (f(data, 0, 9) for f in (oracle.column_max, oracle.column_min, oracle.column_mean))
+        assert cmax[10, 10] == 90.0 and np.isnan(cmax[0, 0])
+        assert cmin[10, 10] == 0.0 and np.isnan(cmin[0, 0])
+        np.testing.assert_almost_equal(cmean[10, 10], 45.0, decimal=1)
+        assert np.isnan(cmean[0, 0])
+        arg = oracle.column_argmax(data, 0, 9)
+        assert arg[10, 10] == 9 and arg[0, 0] == -1 and arg.dtype == np.int32
+        part = np.ones((10, 50, 50), dtype=np.float32) * 10.0
+        part[0:3] = np.nan
+        assert np.all(oracle.column_max(part, 0, 9)[10:20, 10:20] == 10.0)
+        assert np.all(oracle.column_argmax(part, 0, 9) == 3)   # first level attaining the max
+
+    def test_cappi_out_of_range_and_dtype(self):  # test_radar_grid_products.py:190-226
+        grid = np.random.default_rng(0).random((10, 50, 50)).astype(np.float32)
+        assert np.all(np.isnan(oracle.cappi(grid, (0.0, 10000.0), 15000.0)))
+        c = oracle.cappi(grid, (0.0, 10000.0), 5000.0)
+        assert c.shape == (50, 50) and c.dtype == np.float32
+
+
+# ------------------------------------------------------------------------------------------------
+# 2. golden vectors from the reference itself
+# ------------------------------------------------------------------------------------------------
+GEOM_CASES = golden_names("g2_") + golden_names("g3_") + golden_names("g4_") + golden_names("g6_")
+
+
+def _canon(indptr, idx, w):
+    return oracle.canonical_rows(indptr, idx, w)
+
+
+@pytest.mark.parametrize("name", GEOM_CASES)
+def test_builder_matches_reference_csr(name):
+    """Neighbour sets identical; weights bit-identical for cressman/nearest and within 1 float32 ulp for
+    barnes2 (both sides evaluate exp() in float64, then round)."""
+    meta, ref = load_golden(name)
+    vol = volume_for(meta)
+    shape, limits = grid_spec(meta)
+    indptr, idx, w = oracle.build_geometry(vol.gate_x, vol.gate_y, vol.gate_z, shape, limits, **builder_kwargs(meta))
+    r_ip, r_idx, r_w = _canon(ref["indptr"], reference_indices(name, meta, ref), ref["weights"])
+    np.testing.assert_array_equal(indptr, r_ip.astype(np.int64))
+    np.testing.assert_array_equal(idx, r_idx)
+    if meta["weighting"] == "barnes2":
+        ulp = np.abs(w.view(np.int32).astype(np.int64) - r_w.view(np.int32).astype(np.int64))
+        assert ulp.max(initial=0) <= 1
+        assert (ulp > 0).mean() < 1e-4 if ulp.size else True
+    else:
+        np.testing.assert_array_equal(w, r_w)
+
+
+@pytest.mark.parametrize("name", golden_names("g2_") + golden_names("g3_") + golden_names("g6_"))
+def test_csr_apply_matches_reference_grids(name):
+    """Oracle apply on the REFERENCE's CSR (same row order) reproduces the reference grids bit for bit;
+    with the QC filter and with a custom fill value too."""
+    meta, ref = load_golden(name)
+    vol = volume_for(meta)
+    shape, _ = grid_spec(meta)
+    idx = reference_indices(name, meta, ref)
+    qc = None
+    if "qc" in meta:
+        qc = oracle.gate_mask("below", np.ma.getdata(vol.fields[meta["qc"][0]]), meta["qc"][1])
+        assert int(qc.sum()) == int(ref["qc_excluded_count"][0])
+    for fname in meta["fields"]:
+        data, mask = oracle.merge_masks(vol.fields[fname])
+        got = oracle.csr_apply(ref["indptr"], idx, ref["weights"], data, mask, shape)
+        np.testing.assert_array_equal(got, ref[f"grid_{fname}"])
+        if qc is not None:
+            _, mask_qc = oracle.merge_masks(vol.fields[fname], [qc])
+            got = oracle.csr_apply(ref["indptr"], idx, ref["weights"], data, mask_qc, shape)
+            np.testing.assert_array_equal(got, ref[f"grid_{fname}_qc"])
+        if f"grid_{fname}_fill" in ref:
+            got = oracle.csr_apply(ref["indptr"], idx, ref["weights"], data, mask, shape, fill_value=-9999.0)
+            np.testing.assert_array_equal(got, ref[f"grid_{fname}_fill"])
+
+
+@pytest.mark.parametrize("name", golden_names("g3_c2_r150") + golden_names("g3_c2_r060"))
+def test_f64_yardstick_within_tolerance(name):
+    """The float64-accumulating variant (what the GPU computes) stays within the parity tolerance of the
+    reference's float32 pairwise sums: rtol 1e-5 with an absolute floor of 1e-5 * max|field|."""
+    meta, ref = load_golden(name)
+    vol = volume_for(meta)
+    shape, _ = grid_spec(meta)
+    idx = reference_indices(name, meta, ref)
+    for fname in meta["fields"]:
+        data, mask = oracle.merge_masks(vol.fields[fname])
+        got = oracle.csr_apply_f64(ref["indptr"], idx, ref["weights"], data, mask, shape)
+        want = ref[f"grid_{fname}"]
+        np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+        atol = 1e-5 * float(np.nanmax(np.abs(data[~mask])))
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=atol, equal_nan=True)
+
+
+def _product_checks(prefix, grid, z_limits, ref):
+    nz = grid.shape[0]
+    eq = np.testing.assert_array_equal
+    eq(oracle.cappi(grid, z_limits, 4000.0, "linear"), ref[f"{prefix}_cappi4000_linear"])
+    eq(oracle.cappi(grid, z_limits, 4000.0, "nearest"), ref[f"{prefix}_cappi4000_nearest"])
+    eq(oracle.cappi(grid, z_limits, 2500.0, "linear"), ref[f"{prefix}_cappi2500_linear"])
+    eq(oracle.cappi(grid, z_limits, 99000.0, "linear"), ref[f"{prefix}_cappi_above"])
+    lo, hi = oracle.column_range(nz)
+    eq(oracle.column_max(grid, lo, hi), ref[f"{prefix}_colmax"])
+    eq(oracle.column_min(grid, lo, hi), ref[f"{prefix}_colmin"])
+    eq(oracle.column_mean(grid, lo, hi), ref[f"{prefix}_colmean"])
+    lo, hi = oracle.column_range(nz, z_min_alt=1000, z_max_alt=8000, z_limits=z_limits)
+    eq(oracle.column_max(grid, lo, hi), ref[f"{prefix}_colmax_alt"])
+    eq(oracle.column_mean(grid, lo, hi), ref[f"{prefix}_colmean_alt"])
+    lo, hi = oracle.column_range(nz, z_min_idx=2, z_max_idx=6)
+    eq(oracle.column_max(grid, lo, hi), ref[f"{prefix}_colmax_idx"])
+    # argmax contract is build-defined; it must at least select the reference's max values
+    arg = oracle.column_argmax(grid, 0, nz - 1)
+    cmax = ref[f"{prefix}_colmax"]
+    has = arg >= 0
+    eq(has, ~np.isnan(cmax))
+    yy, xx = np.nonzero(has)
+    eq(grid[arg[yy, xx], yy, xx], cmax[yy, xx])
+
+
+@pytest.mark.parametrize("name", golden_names("g5_"))
+def test_products_match_reference(name):
+    meta, ref = load_golden(name)
+    _product_checks("P", ref["grid"], tuple(meta["z_limits"]), ref)
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names("g3_") if n.endswith("barnes2")])
+def test_products_on_gridded_windows(name):
+    meta, ref = load_golden(name)
+    _, limits = grid_spec(meta)
+    _product_checks("DBZH", ref["grid_DBZH"], limits[0], ref)
+
+
+def test_exact_level_cappi_plan():
+    """z 0..19 km / 20 levels puts 4000 m exactly on level 4 (view, no arithmetic); z 0..15 km does not."""
+    assert oracle.cappi_plan((0.0, 19000.0), 20, 4000.0) == ("level", 4)
+    plan = oracle.cappi_plan((0.0, 15000.0), 20, 4000.0)
+    assert plan[0] == "lerp" and plan[1] == 5 and abs(plan[3] - (4000.0 / (15000.0 / 19) - 5)) < 1e-12
+
+
+def test_antenna_transform_agrees_with_package():
+    """Two independent restatements of PyART's published model (parity unpinned vs PyART itself)."""
+    from radar_processor_amd import synthetic
+    r = np.linspace(120.0, 240e3, 50)[None, :]
+    az = np.array([0.0, 33.0, 181.5, 359.0])[:, None]
+    el = np.array([0.5, 3.0, 11.8, 25.0])[:, None]
+    for a, b in zip(oracle.antenna_to_cartesian(r, az, el), synthetic.antenna_to_cartesian(r, az, el)):
+        np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-6)
