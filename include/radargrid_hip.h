@@ -171,6 +171,20 @@ int rg_geom_fill_f32(const rg_gate4* sorted_gates, const int32_t* cell_start, co
                      double min_radius, double beam_factor, int32_t weighting, const int64_t* indptr,
                      int32_t* gate_idx, float* weights, rg_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * K2  fused on-the-fly gridding: the neighbour search of rg_geom_count/fill_f32 fused with the masked
+ * weighted mean of rg_csr_apply_f32 -- radar_grid/compute.py:46-91 + radar_grid/interpolate.py:69-104 in
+ * one kernel, no CSR in memory (for grids whose pair count makes the CSR pointless or impossible,
+ * SURVEY.md F6).  Same neighbour sets and weights as the builder; results differ from the CSR path only by
+ * float64 summation order.  `packed` is the rg_pack_fields_f32 layout over the same gate numbering as the
+ * gates that were binned.
+ * ------------------------------------------------------------------------------------------------- */
+int rg_roi_grid_f32(const rg_gate4* sorted_gates, const int32_t* cell_start, const rg_cellgrid* cells_host,
+                    const float* xc, const float* yc, const float* zc, int32_t nz, int32_t ny, int32_t nx,
+                    double min_radius, double beam_factor, int32_t weighting,
+                    const float* packed, int32_t n_fields, int32_t stride, float fill_value, float* out,
+                    rg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,1 +1,40 @@
-"""placeholder; filled in below"""
+"""radar_processor_amd -- MI355X-native implementation of the ``radar_grid`` hot path of
+jgmarti84/radar-processor: geometry build -> CSR apply -> CAPPI / COLMAX, behind the reference's own Python
+function surface (``radar_grid/__init__.py:39-82``, hot-path names only).
+
+    from radar_processor_amd import (GridGeometry, compute_grid_geometry, apply_geometry, apply_geometry_multi,
+                                     GateFilter, constant_altitude_ppi, column_max, save_geometry, load_geometry)
+
+Host code is Python on PyTorch-ROCm tensors (allocations + streams only); the work is done by hand-written HIP
+kernels for gfx950 in ``csrc/`` behind the C ABI of ``include/radargrid_hip.h``.  There is no CPU fallback:
+without the built library and a HIP device every compute entry point raises ``NativeUnavailable``.
+
+(The directory is spelled ``radar_processor_amd`` because a hyphen cannot appear in a Python package name;
+``radar-processor_amd`` at the repository root is a symlink to it.)
+"""
+from ._native import NativeError, NativeUnavailable, load_library
+from .gate_filters import GateFilter, create_mask_from_filter, device_gate_mask
+from .geometry_builder import RoiSearch, compute_grid_geometry
+from .grid_geometry import DeviceCSR, GridGeometry, load_geometry, save_geometry
+from .grid_products import (EARTH_RADIUS, EFFECTIVE_RADIUS_FACTOR, column_argmax, column_max, column_mean,
+                            column_min, constant_altitude_ppi)
+from .gridding import apply_geometry, apply_geometry_multi, grid_fields_device
+from .roi_grid import roi_grid_fields_device
+from .radar_adaptors import (get_available_fields, get_field_data, get_gate_coordinates, get_radar_altitude,
+                             get_radar_info)
+
+__version__ = "0.1.0"
+
+__all__ = [
+    # reference surface (radar_grid/__init__.py:39-82), hot-path subset
+    "GridGeometry", "save_geometry", "load_geometry",
+    "compute_grid_geometry",
+    "apply_geometry", "apply_geometry_multi",
+    "get_gate_coordinates", "get_field_data", "get_available_fields", "get_radar_info", "get_radar_altitude",
+    "GateFilter", "create_mask_from_filter",
+    "constant_altitude_ppi", "column_max", "column_min", "column_mean",
+    "EARTH_RADIUS", "EFFECTIVE_RADIUS_FACTOR",
+    # build-specific additions
+    "column_argmax", "grid_fields_device", "roi_grid_fields_device", "device_gate_mask", "RoiSearch", "DeviceCSR",
+    "NativeUnavailable", "NativeError", "load_library",
+]

@@ -87,8 +87,6 @@ def load_library(require_device: bool = True):
                 try:
                     fn = getattr(lib, name)
                 except AttributeError:
-                    if name == "rg_roi_grid_f32":  # optional until the fused gridder lands
-                        continue
                     raise NativeUnavailable(f"{LIB_PATH} does not export {name}") from None
                 fn.restype = restype
                 fn.argtypes = argtypes

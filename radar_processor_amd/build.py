@@ -25,7 +25,7 @@ SOURCES = [
     ("rg_csr_apply.hip", []),
     ("rg_products.hip", []),
     ("rg_geometry.hip", ["-ffp-contract=off"]),
-    ("rg_roi_grid.hip", []),
+    ("rg_roi_grid.hip", ["-ffp-contract=off"]),
 ]
 
 
@@ -46,7 +46,8 @@ def _stale(target: str, deps: List[str]) -> bool:
 def build(force: bool = False, verbose: bool = True) -> str:
     """Compile every HIP source for gfx950 and link the shared library. Returns its path."""
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "rg_common.hpp"), os.path.join(INCLUDE, "radargrid_hip.h")]
+    headers = [os.path.join(CSRC, "rg_common.hpp"), os.path.join(CSRC, "rg_roi_search.hpp"),
+               os.path.join(INCLUDE, "radargrid_hip.h")]
     common = ["-std=c++17", "-O3", f"--offload-arch={ARCH}", "-fPIC",
               f"-I{INCLUDE}", f"-I{CSRC}", "-Wall", "-Wno-unused-result"]
     objs = []

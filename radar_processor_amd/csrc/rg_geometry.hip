@@ -23,29 +23,11 @@
 #include <rocprim/iterator/transform_iterator.hpp>
 
 #include "rg_common.hpp"
+#include "rg_roi_search.hpp"
 
 namespace {
 
-constexpr int kVoxPerWave = 8;
-
-struct Cells {
-  double x0, y0, inv_cx, inv_cy, z_lo, z_hi;
-  int ncx, ncy;
-};
-
-inline Cells to_cells(const rg_cellgrid* c) {
-  Cells r;
-  r.x0 = c->x0; r.y0 = c->y0; r.inv_cx = c->inv_cx; r.inv_cy = c->inv_cy; r.z_lo = c->z_lo; r.z_hi = c->z_hi;
-  r.ncx = c->ncx; r.ncy = c->ncy;
-  return r;
-}
-
-__device__ __forceinline__ double cell_coord(double g, double origin, double inv) { return floor((g - origin) * inv); }
-
-__device__ __forceinline__ int cell_clamped(double g, double origin, double inv, int n) {
-  const double t = cell_coord(g, origin, inv);
-  return t < 0.0 ? 0 : (t >= (double)n ? n - 1 : (int)t);
-}
+using namespace rg::roi;
 
 // ---- binning ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(rg::kBlock) void bin_keys_kernel(const float* __restrict__ gx, const float* __restrict__ gy,
@@ -95,30 +77,6 @@ __global__ __launch_bounds__(rg::kBlock) void gather_sorted_kernel(const unsigne
   sorted[j] = r;
 }
 
-// ---- ROI search ------------------------------------------------------------------------------------
-struct SearchArgs {
-  const rg_gate4* sorted;
-  const int* cell_start;
-  Cells c;
-  const float* xc;
-  const float* yc;
-  const float* zc;
-  int nz, ny, nx;
-  long n_vox;
-  double min_radius, beam_factor;
-};
-
-template <int W>
-__device__ __forceinline__ float roi_weight(double d2, double r2) {
-  if constexpr (W == RG_W_BARNES2) {
-    return (float)(exp(-d2 / (r2 / 4.0)) + 1e-5);  // compute.py:83
-  } else if constexpr (W == RG_W_CRESSMAN) {
-    return (float)((r2 - d2) / (r2 + d2));         // compute.py:85
-  } else {
-    return 1.0f;                                    // compute.py:87 ('nearest' = uniform mean)
-  }
-}
-
 constexpr int kCount = 0, kFill = 1;
 
 template <int MODE, int W>
@@ -132,18 +90,9 @@ __global__ __launch_bounds__(rg::kBlock) void roi_kernel(SearchArgs a, int* __re
   for (int t = 0; t < kVoxPerWave; ++t) {
     const long v = vbeg + t;
     if (v >= a.n_vox) break;  // wave-uniform
-    const int ix = (int)(v % a.nx);
-    const long q = v / a.nx;
-    const int iy = (int)(q % a.ny);
-    const int iz = (int)(q / a.ny);
-    const double x = (double)a.xc[ix], y = (double)a.yc[iy], z = (double)a.zc[iz];
-    const double dist = sqrt(x * x + y * y + z * z);               // compute.py:46
-    const double r = fmax(a.min_radius, dist * a.beam_factor);     // compute.py:47
-    const double r2 = r * r;                                       // compute.py:57
-    const int cx0 = __builtin_amdgcn_readfirstlane(cell_clamped(x - r, a.c.x0, a.c.inv_cx, a.c.ncx));
-    const int cx1 = __builtin_amdgcn_readfirstlane(cell_clamped(x + r, a.c.x0, a.c.inv_cx, a.c.ncx));
-    const int cy0 = __builtin_amdgcn_readfirstlane(cell_clamped(y - r, a.c.y0, a.c.inv_cy, a.c.ncy));
-    const int cy1 = __builtin_amdgcn_readfirstlane(cell_clamped(y + r, a.c.y0, a.c.inv_cy, a.c.ncy));
+    const VoxelBox b = voxel_box(a, v);
+    const double x = b.x, y = b.y, z = b.z, r2 = b.r2;
+    const int cx0 = b.cx0, cx1 = b.cx1, cy0 = b.cy0, cy1 = b.cy1;
     int count = 0;
     long long base = 0;
     if constexpr (MODE == kFill) base = indptr[v];
@@ -197,31 +146,6 @@ unsigned key_bits(unsigned n_cells) {
   unsigned b = 1;
   while (b < 32 && (1ull << b) <= n_cells) ++b;
   return b;
-}
-
-int check_search_args(const char* fn, const rg_gate4* sorted, const int32_t* cell_start, const rg_cellgrid* cells,
-                      const float* xc, const float* yc, const float* zc, int nz, int ny, int nx) {
-  RG_REQUIRE(sorted && cell_start && cells && xc && yc && zc, RG_EINVAL, "%s: null pointer", fn);
-  RG_REQUIRE(nz >= 1 && ny >= 1 && nx >= 1, RG_EINVAL, "%s: bad grid shape (%d,%d,%d)", fn, nz, ny, nx);
-  RG_REQUIRE(cells->ncx >= 1 && cells->ncy >= 1 && (long)cells->ncx * cells->ncy < 0x7FFFFFFFL, RG_EINVAL,
-             "%s: bad cell grid %dx%d", fn, cells->ncx, cells->ncy);
-  RG_REQUIRE(rg::aligned16(sorted), RG_EALIGN, "%s: sorted_gates must be 16-byte aligned", fn);
-  return RG_OK;
-}
-
-SearchArgs make_args(const rg_gate4* sorted, const int32_t* cell_start, const rg_cellgrid* cells, const float* xc,
-                     const float* yc, const float* zc, int nz, int ny, int nx, double min_radius, double beam_factor) {
-  SearchArgs a;
-  a.sorted = sorted; a.cell_start = cell_start; a.c = to_cells(cells);
-  a.xc = xc; a.yc = yc; a.zc = zc; a.nz = nz; a.ny = ny; a.nx = nx;
-  a.n_vox = (long)nz * ny * nx;
-  a.min_radius = min_radius; a.beam_factor = beam_factor;
-  return a;
-}
-
-inline dim3 search_grid(long n_vox) {
-  const long waves = (n_vox + kVoxPerWave - 1) / kVoxPerWave;
-  return dim3((unsigned)((waves + 3) / 4));
 }
 
 }  // namespace

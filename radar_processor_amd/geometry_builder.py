@@ -1,0 +1,194 @@
+"""GPU geometry builder -- mirror of ``radar_grid/compute.py`` (``compute_grid_geometry`` :106-284,
+``_process_single_level`` :18-103).
+
+The reference builds a cKDTree per z-level and walks every voxel in a Python loop, exchanging levels through
+temp ``.npz`` files.  Here the whole build is three kernels on the device (csrc/rg_geometry.hip):
+bucket + radix-sort the gates into a cell grid, count every voxel's neighbours, prefix-sum, fill.  Membership
+(``z_rel <= toa`` and ``d2 < r2``) and the weights are evaluated in the reference's float64 arithmetic from the
+same float32 inputs, so the neighbour sets are identical and the weights agree to the last float32 bit
+(Barnes: up to 1 ulp where the two ``exp`` implementations round differently).  Row order inside a voxel is
+(cell row, gate index) instead of KD-tree traversal order.
+
+:class:`RoiSearch` keeps the sorted-gate structure so the same search can also feed the fused on-the-fly
+gridder (``roi_grid.py``) without materialising a CSR.
+"""
+from __future__ import annotations
+
+import logging
+import math
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _native
+from .grid_geometry import DeviceCSR, GridGeometry
+
+logger = logging.getLogger("radar_grid.compute")
+
+_INT32_MAX = np.iinfo(np.int32).max
+WEIGHTINGS = ("barnes2", "cressman", "nearest")
+
+
+def _as_device_f32(a, dev):
+    torch = _native.torch_mod()
+    if type(a).__module__.startswith("torch"):
+        return a.to(device=dev, dtype=torch.float32).contiguous().view(-1)
+    arr = np.asarray(a)
+    if arr.dtype != np.float32:
+        logger.warning("gate coordinates are %s; rounding to float32 as get_gate_coordinates() does", arr.dtype)
+    return torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32).ravel()).to(dev)
+
+
+class RoiSearch:
+    """Cell-sorted gates + voxel coordinate tables in HBM: everything the ROI search kernels need."""
+
+    def __init__(self, gate_x, gate_y, gate_z, grid_shape, grid_limits, radar_altitude=0.0, min_radius=250.0,
+                 beam_factor=0.01746, toa=17000.0, device=None, cell_size: Optional[float] = None):
+        torch = _native.torch_mod()
+        lib = _native.load_library()
+        self.dev = _native.device() if device is None else device
+        self.grid_shape = tuple(int(s) for s in grid_shape)
+        self.grid_limits = grid_limits
+        self.min_radius = float(min_radius)
+        self.beam_factor = float(beam_factor)
+        self.toa = toa
+        nz, ny, nx = self.grid_shape
+
+        gx = _as_device_f32(gate_x, self.dev)
+        gy = _as_device_f32(gate_y, self.dev)
+        gz = _as_device_f32(gate_z, self.dev)
+        if not (gx.numel() == gy.numel() == gz.numel()):
+            raise ValueError("gate_x, gate_y and gate_z differ in length")
+        self.n_gates = int(gx.numel())
+
+        # compute.py:184-186 -- float32 linspace tables (NumPy's own rounding; never re-derived on the device)
+        zc = np.linspace(grid_limits[0][0], grid_limits[0][1], nz, dtype="float32")
+        yc = np.linspace(grid_limits[1][0], grid_limits[1][1], ny, dtype="float32")
+        xc = np.linspace(grid_limits[2][0], grid_limits[2][1], nx, dtype="float32")
+        self.zc, self.yc, self.xc = (torch.from_numpy(c).to(self.dev) for c in (zc, yc, xc))
+
+        # largest ROI over the grid (reached at a corner), padded so dropped gates provably cannot be neighbours
+        far = math.sqrt(max(abs(float(xc.min())), abs(float(xc.max()))) ** 2
+                        + max(abs(float(yc.min())), abs(float(yc.max()))) ** 2
+                        + max(abs(float(zc.min())), abs(float(zc.max()))) ** 2)
+        r_max = max(self.min_radius, far * abs(self.beam_factor)) * (1.0 + 1e-6) + 1.0
+        self.r_max = r_max
+        x_lo, x_hi = float(xc.min()) - r_max, float(xc.max()) + r_max
+        y_lo, y_hi = float(yc.min()) - r_max, float(yc.max()) + r_max
+
+        if cell_size is None:
+            cell_size = self._auto_cell(gx, gy, x_lo, x_hi, y_lo, y_hi)
+        # keep the cell table small (int32 entries): at most ~16 M cells
+        span = max(x_hi - x_lo, y_hi - y_lo)
+        cell_size = max(float(cell_size), span / 4000.0, 1.0)
+        self.cell_size = cell_size
+        ncx = max(1, int(math.ceil((x_hi - x_lo) / cell_size)))
+        ncy = max(1, int(math.ceil((y_hi - y_lo) / cell_size)))
+        self.cells = _native.CellGrid(x0=x_lo, y0=y_lo, inv_cx=1.0 / cell_size, inv_cy=1.0 / cell_size,
+                                      z_lo=float(zc.min()) - r_max, z_hi=float(zc.max()) + r_max, ncx=ncx, ncy=ncy)
+
+        self.sorted_gates = torch.empty(max(self.n_gates, 1) * 4, dtype=torch.float32, device=self.dev)
+        self.cell_start = torch.empty(ncx * ncy + 1, dtype=torch.int32, device=self.dev)
+        ws_bytes = int(lib.rg_geom_bin_workspace_bytes(self.n_gates, ncx, ncy))
+        if ws_bytes < 0:
+            raise _native.NativeError("rg_geom_bin_workspace_bytes rejected its arguments")
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.dev)
+        with torch.cuda.device(self.dev):
+            _native.check(lib.rg_geom_bin_gates_f32(
+                _native.ptr(gx), _native.ptr(gy), _native.ptr(gz), self.n_gates,
+                float(np.float32(radar_altitude)), float(np.float32(toa)), self.cells,
+                _native.ptr(self.sorted_gates), _native.ptr(self.cell_start), _native.ptr(ws), ws_bytes,
+                _native.stream_ptr()), "rg_geom_bin_gates_f32")
+            self.n_binned = int(self.cell_start[-1].item())
+        del ws
+
+    def _auto_cell(self, gx, gy, x_lo, x_hi, y_lo, y_hi) -> float:
+        """Cell size for which one cell row of a typical voxel's search box holds about one wavefront (64) of
+        candidates.  For polar data the areal gate density falls off as 1/D while the ROI grows as D, so
+        ``2*beam_factor*cell * N / (2*pi*R_max)`` candidates per row, independent of range."""
+        torch = _native.torch_mod()
+        if self.n_gates == 0:
+            return max(self.min_radius, 1.0)
+        ground = torch.sqrt(gx * gx + gy * gy)
+        r_gate = float(torch.nan_to_num(ground, nan=0.0, posinf=0.0).max().item())
+        n = self.n_gates
+        bf = max(abs(self.beam_factor), 1e-6)
+        cell = 64.0 * math.pi * max(r_gate, 1.0) / (bf * n)
+        return float(min(max(cell, 0.25 * self.min_radius, 25.0), 8.0 * max(self.min_radius, 1.0) + 2000.0))
+
+    # ------------------------------------------------------------------------------------------------
+    def build_csr(self, weighting: str = "barnes2") -> DeviceCSR:
+        torch = _native.torch_mod()
+        lib = _native.load_library()
+        nz, ny, nx = self.grid_shape
+        n_vox = nz * ny * nx
+        with torch.cuda.device(self.dev):
+            stream = _native.stream_ptr()
+            counts = torch.zeros(n_vox + 1, dtype=torch.int32, device=self.dev)
+            _native.check(lib.rg_geom_count_f32(
+                _native.ptr(self.sorted_gates), _native.ptr(self.cell_start), self.cells, _native.ptr(self.xc),
+                _native.ptr(self.yc), _native.ptr(self.zc), nz, ny, nx, self.min_radius, self.beam_factor,
+                _native.ptr(counts), stream), "rg_geom_count_f32")
+            indptr = torch.empty(n_vox + 1, dtype=torch.int64, device=self.dev)
+            ws_bytes = int(lib.rg_scan_workspace_bytes(n_vox))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.dev)
+            _native.check(lib.rg_scan_counts_i64(_native.ptr(counts), n_vox, _native.ptr(indptr), _native.ptr(ws),
+                                                 ws_bytes, stream), "rg_scan_counts_i64")
+            n_pairs = int(indptr[-1].item())
+            del counts, ws
+            gate_idx = torch.empty(max(n_pairs, 1), dtype=torch.int32, device=self.dev)[:n_pairs]
+            weights = torch.empty(max(n_pairs, 1), dtype=torch.float32, device=self.dev)[:n_pairs]
+            if n_pairs:
+                _native.check(lib.rg_geom_fill_f32(
+                    _native.ptr(self.sorted_gates), _native.ptr(self.cell_start), self.cells, _native.ptr(self.xc),
+                    _native.ptr(self.yc), _native.ptr(self.zc), nz, ny, nx, self.min_radius, self.beam_factor,
+                    _native.WEIGHTINGS[weighting], _native.ptr(indptr), _native.ptr(gate_idx), _native.ptr(weights),
+                    stream), "rg_geom_fill_f32")
+            if n_pairs <= _INT32_MAX:
+                indptr = indptr.to(torch.int32)   # the reference's dtype (compute.py:232) whenever it fits
+            max_gate = int(gate_idx.max().item()) if n_pairs else -1
+        return DeviceCSR(indptr, gate_idx, weights, max_gate)
+
+
+def compute_grid_geometry(
+    gate_x: np.ndarray,
+    gate_y: np.ndarray,
+    gate_z: np.ndarray,
+    grid_shape: Tuple[int, int, int],
+    grid_limits: Tuple[Tuple[float, float], ...],
+    temp_dir: str,
+    radar_altitude: float = 0.0,
+    min_radius: float = 250.0,
+    beam_factor: float = 0.01746,
+    weighting: str = "barnes2",
+    toa: float = 17000.0,
+    n_workers: Optional[int] = None,
+) -> GridGeometry:
+    """Precompute which gates contribute to each voxel and with what weight
+    (``radar_grid/compute.py:106-284``; same signature).
+
+    ``temp_dir`` and ``n_workers`` are accepted for compatibility: the directory must exist (the reference
+    raises ``ValueError`` otherwise, compute.py:173-174) but nothing is written to it, and there is no worker
+    pool -- the build runs on the GPU.  The result is device resident; ``.indptr`` / ``.gate_indices`` /
+    ``.weights`` copy to the host on first access (``save_geometry`` does that).
+
+    Reference quirks kept on purpose: ``radar_altitude`` is subtracted from ``gate_z``
+    in float32 (compute.py:182), the returned geometry does not carry it (compute.py:277-284 => 0.0), and
+    ``'nearest'`` means a uniform mean over the ROI, not the nearest gate (compute.py:86-87).
+    """
+    if not os.path.isdir(temp_dir):
+        raise ValueError(f"temp_dir does not exist: {temp_dir}")
+    if weighting not in WEIGHTINGS:
+        raise ValueError(f"Unknown weighting function: {weighting}")
+
+    search = RoiSearch(gate_x, gate_y, gate_z, grid_shape, grid_limits, radar_altitude=radar_altitude,
+                       min_radius=min_radius, beam_factor=beam_factor, toa=toa)
+    nz, ny, nx = search.grid_shape
+    logger.info(f"Radar altitude: {radar_altitude:.1f} m")
+    logger.info(f"TOA filter: {search.n_binned:,} of {search.n_gates:,} gates kept (below {toa}m and within reach "
+                f"of the grid); cell size {search.cell_size:.0f} m")
+    logger.info(f"Processing {nz} z-levels on {search.dev}...")
+    csr = search.build_csr(weighting)
+    logger.info(f"Geometry complete ({csr.n_pairs:,} total pairs).")
+    return GridGeometry.from_device(grid_shape, grid_limits, csr, toa)

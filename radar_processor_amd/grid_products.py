@@ -1,0 +1,165 @@
+"""2-D products collapsed from a 3-D grid -- mirror of ``radar_grid/products.py``:
+``constant_altitude_ppi`` (CAPPI, :317-415), ``column_max`` / ``column_min`` / ``column_mean`` (:420-580) and,
+new in this build, ``column_argmax``.
+
+The scalar control flow (level search, altitude -> index conversion, error handling) stays on the host exactly
+as in the reference; the per-pixel arithmetic runs in ``rg_cappi_lerp_f32`` / ``rg_column_reduce_f32``
+(csrc/rg_products.hip).  Inputs may be NumPy arrays (staged to HBM and back, NumPy result) or cuda float32
+tensors (result stays in HBM).
+"""
+from __future__ import annotations
+
+import logging
+from typing import Optional
+
+import numpy as np
+
+from . import _native
+from .grid_geometry import GridGeometry
+
+logger = logging.getLogger("radar_grid.products")
+
+EARTH_RADIUS = 6371000.0            # radar_grid/products.py:19
+EFFECTIVE_RADIUS_FACTOR = 4.0 / 3.0  # radar_grid/products.py:20
+
+
+def _is_tensor(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+def _to_device_grid(grid):
+    """Returns (cuda float32 contiguous tensor [nz, ny, nx], came_from_numpy)."""
+    torch = _native.torch_mod()
+    if _is_tensor(grid):
+        if not grid.is_cuda:
+            raise _native.NativeUnavailable("products run on the GPU: pass a cuda tensor or a NumPy array")
+        if grid.dtype != torch.float32:
+            raise ValueError("device grids must be float32")
+        return grid.contiguous(), False
+    dev = _native.device()
+    if isinstance(grid, np.ma.MaskedArray):
+        grid = np.ma.getdata(grid)   # the reference's arithmetic also acts on the raw data (products.py:407-411)
+    arr = np.ascontiguousarray(grid, dtype=np.float32)
+    if arr.ndim != 3:
+        raise ValueError("grid must have shape (nz, ny, nx)")
+    return torch.from_numpy(arr).to(dev), True
+
+
+def _finish(t, as_numpy: bool):
+    return t.cpu().numpy() if as_numpy else t
+
+
+def constant_altitude_ppi(grid, geometry: GridGeometry, altitude: float, interpolation: str = "linear"):
+    """CAPPI at ``altitude`` metres (``radar_grid/products.py:317-415``).
+
+    Out of ``[z_min, z_max]`` -> warning + all-NaN float32; ``'nearest'`` and an exact level hit return that
+    level of ``grid`` (a view, like the reference); otherwise the float32 lerp of the two bracketing levels.
+    """
+    nz, ny, nx = geometry.grid_shape
+    z_min, z_max = geometry.grid_limits[0]
+    z_coords = np.linspace(z_min, z_max, nz, dtype="float32")
+
+    if altitude < z_min or altitude > z_max:
+        logger.warning(f"Altitude {altitude}m is outside grid range [{z_min}, {z_max}]m")
+        if _is_tensor(grid):
+            return grid.new_full((ny, nx), float("nan"))
+        return np.full((ny, nx), np.nan, dtype="float32")
+
+    if interpolation == "nearest":
+        return grid[int(np.argmin(np.abs(z_coords - altitude))), :, :]
+    if interpolation != "linear":
+        raise ValueError(f"Unknown interpolation method: {interpolation}")
+
+    z_matches = np.isclose(z_coords, altitude, rtol=1e-6)
+    if np.any(z_matches):
+        return grid[int(np.where(z_matches)[0][0]), :, :]
+
+    z_step = (z_max - z_min) / (nz - 1) if nz > 1 else 1.0
+    z_frac = (altitude - z_min) / z_step
+    z_low = int(np.floor(z_frac))
+    if z_low < 0:
+        return grid[0, :, :]
+    if z_low + 1 >= nz:
+        return grid[nz - 1, :, :]
+    weight_high = z_frac - z_low
+    weight_low = 1.0 - weight_high
+
+    torch = _native.torch_mod()
+    lib = _native.load_library()
+    g, as_numpy = _to_device_grid(grid)
+    out = torch.empty((ny, nx), dtype=torch.float32, device=g.device)
+    with torch.cuda.device(g.device):
+        # weak Python-float weights act as float32 under NumPy >= 2
+        _native.check(lib.rg_cappi_lerp_f32(_native.ptr(g), ny * nx, z_low, float(np.float32(weight_low)),
+                                            float(np.float32(weight_high)), _native.ptr(out), _native.stream_ptr()),
+                      "rg_cappi_lerp_f32")
+    return _finish(out, as_numpy)
+
+
+def _level_window(nz, z_min_idx, z_max_idx, z_min_alt, z_max_alt, geometry):
+    """Index window of the column products (``products.py:462-485``)."""
+    if z_min_alt is not None or z_max_alt is not None:
+        if geometry is None:
+            raise ValueError("geometry is required when using altitude-based limits")
+        z_lo, z_hi = geometry.grid_limits[0]
+        z_coords = np.linspace(z_lo, z_hi, nz)
+        if z_min_alt is not None:
+            z_min_idx = int(np.searchsorted(z_coords, z_min_alt))
+        if z_max_alt is not None:
+            z_max_idx = int(np.searchsorted(z_coords, z_max_alt, side="right")) - 1
+    if z_min_idx is None:
+        z_min_idx = 0
+    if z_max_idx is None:
+        z_max_idx = nz - 1
+    return max(0, z_min_idx), min(nz - 1, z_max_idx)
+
+
+def _column(op: str, grid, z_min_idx, z_max_idx, z_min_alt, z_max_alt, geometry, want_arg=False):
+    nz = int(grid.shape[0])
+    lo, hi = _level_window(nz, z_min_idx, z_max_idx, z_min_alt, z_max_alt, geometry)
+    if lo > hi:
+        raise ValueError(f"empty level window [{lo}, {hi}]")   # np.nanmax raises on a zero-size slice too
+    torch = _native.torch_mod()
+    lib = _native.load_library()
+    g, as_numpy = _to_device_grid(grid)
+    ny, nx = int(g.shape[1]), int(g.shape[2])
+    out = torch.empty((ny, nx), dtype=torch.float32, device=g.device)
+    arg = torch.empty((ny, nx), dtype=torch.int32, device=g.device) if want_arg else None
+    with torch.cuda.device(g.device):
+        _native.check(lib.rg_column_reduce_f32(_native.ptr(g), nz, ny * nx, lo, hi, _native.COLUMN_OPS[op],
+                                               _native.ptr(out), _native.ptr(arg), _native.stream_ptr()),
+                      "rg_column_reduce_f32")
+    if want_arg:
+        return _finish(out, as_numpy), _finish(arg, as_numpy)
+    return _finish(out, as_numpy)
+
+
+def column_max(grid, z_min_idx: Optional[int] = None, z_max_idx: Optional[int] = None,
+               z_min_alt: Optional[float] = None, z_max_alt: Optional[float] = None,
+               geometry: Optional[GridGeometry] = None):
+    """COLMAX: NaN-ignoring maximum of every vertical column (``radar_grid/products.py:420-490``); an all-NaN
+    column stays NaN."""
+    return _column("max", grid, z_min_idx, z_max_idx, z_min_alt, z_max_alt, geometry)
+
+
+def column_min(grid, z_min_idx: Optional[int] = None, z_max_idx: Optional[int] = None,
+               z_min_alt: Optional[float] = None, z_max_alt: Optional[float] = None,
+               geometry: Optional[GridGeometry] = None):
+    """NaN-ignoring column minimum (``radar_grid/products.py:493-535``)."""
+    return _column("min", grid, z_min_idx, z_max_idx, z_min_alt, z_max_alt, geometry)
+
+
+def column_mean(grid, z_min_idx: Optional[int] = None, z_max_idx: Optional[int] = None,
+                z_min_alt: Optional[float] = None, z_max_alt: Optional[float] = None,
+                geometry: Optional[GridGeometry] = None):
+    """NaN-ignoring column mean (``radar_grid/products.py:538-580``)."""
+    return _column("mean", grid, z_min_idx, z_max_idx, z_min_alt, z_max_alt, geometry)
+
+
+def column_argmax(grid, z_min_idx: Optional[int] = None, z_max_idx: Optional[int] = None,
+                  z_min_alt: Optional[float] = None, z_max_alt: Optional[float] = None,
+                  geometry: Optional[GridGeometry] = None):
+    """``(colmax, level)``: the column maximum and the int32 index (into the full grid) of the FIRST level that
+    attains it, ``-1`` where the column is all NaN.  Not in the reference: ``np.nanargmax``
+    semantics on the same 3-D grid define the contract."""
+    return _column("max", grid, z_min_idx, z_max_idx, z_min_alt, z_max_alt, geometry, want_arg=True)

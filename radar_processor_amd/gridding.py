@@ -1,0 +1,163 @@
+"""Field gridding through a precomputed geometry -- mirror of ``radar_grid/interpolate.py``
+(``apply_geometry`` :15-104, ``apply_geometry_multi`` :107-142), executed by the HIP kernel
+``rg_csr_apply_f32`` (csrc/rg_csr_apply.hip).
+
+Two layers:
+
+* :func:`apply_geometry` / :func:`apply_geometry_multi` keep the reference signatures (NumPy masked arrays in,
+  float32 ``ndarray`` of ``geometry.grid_shape`` out).  They stage the inputs into HBM, run the kernels and
+  copy the grid back; the geometry itself is uploaded once and cached on the ``GridGeometry`` object.
+* :func:`grid_fields_device` is the device-resident form the batch driver and the benchmark use: field
+  tensors already in HBM in, grid tensor in HBM out, nothing crosses PCIe.
+
+All fields handed to one call are gridded by ONE pass over the CSR (the reference re-reads the CSR per field,
+interpolate.py:137-140): the mask of every field is folded into its values and the fields are interleaved
+gate-major, so each (voxel, gate) pair costs a single gather.
+"""
+from __future__ import annotations
+
+import ctypes
+import logging
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _native
+from .gate_filters import GateFilter
+from .grid_geometry import GridGeometry
+
+logger = logging.getLogger("radar_grid.interpolate")
+
+
+def _stride_for(n_fields: int) -> int:
+    return 1 if n_fields == 1 else 2 if n_fields == 2 else 4 if n_fields <= 4 else 8
+
+
+def _coerce_filters(additional_filters) -> List[GateFilter]:
+    """``None`` -> ``[]``, a bare filter -> ``[gf]``, a list stays, anything else is a ValueError
+    (``interpolate.py:50-56``)."""
+    if isinstance(additional_filters, list):
+        return additional_filters
+    if additional_filters is None:
+        return []
+    if isinstance(additional_filters, GateFilter):
+        return [additional_filters]
+    raise ValueError("additional_filters must be a list of GateFilter objects")
+
+
+def _host_field(field_data, filters: Sequence[GateFilter]):
+    """float32 values + merged exclusion mask (``interpolate.py:59-64``).
+
+    The reference indexes ``np.ma.getmask(field)`` and therefore crashes on inputs without a full mask
+     unless a filter happens to broadcast it; here a missing mask simply means "nothing masked",
+    which is also what the reference computes whenever it does not crash.
+    """
+    values = np.ascontiguousarray(np.ma.getdata(field_data), dtype=np.float32).ravel()
+    mask = np.ma.getmaskarray(field_data).ravel()
+    for gf in filters:
+        mask = mask | gf.gate_excluded
+    return values, np.ascontiguousarray(mask, dtype=np.uint8)
+
+
+def grid_fields_device(geometry: GridGeometry, fields: Sequence, masks: Optional[Sequence] = None,
+                       shared_mask=None, fill_value: float = np.nan, out=None):
+    """Grid ``len(fields)`` device-resident fields with one CSR pass per group of up to 8.
+
+    Parameters
+    ----------
+    fields : sequence of cuda float32 tensors ``[G]``
+    masks : optional sequence (same length) of uint8 tensors ``[G]`` or ``None`` (``1`` = gate excluded)
+    shared_mask : optional uint8 tensor OR-ed into every field's mask (e.g. one QC GateFilter for all)
+    out : optional float32 tensor ``[len(fields), nz, ny, nx]`` to write into
+
+    Returns the ``[F, nz, ny, nx]`` float32 tensor (device).
+    """
+    torch = _native.torch_mod()
+    lib = _native.load_library()
+    n_fields = len(fields)
+    if n_fields == 0:
+        raise ValueError("no fields to grid")
+    dev = fields[0].device
+    if dev.type != "cuda":
+        raise _native.NativeUnavailable("grid_fields_device needs device-resident (cuda) tensors")
+    csr = geometry.device_csr(dev)
+    n_gates = int(fields[0].numel())
+    for i, f in enumerate(fields):
+        if not (f.is_cuda and f.dtype == torch.float32 and f.is_contiguous() and f.numel() == n_gates):
+            raise ValueError(f"field {i}: expected a contiguous cuda float32 tensor of {n_gates} gates")
+    if masks is None:
+        masks = [None] * n_fields
+    if len(masks) != n_fields:
+        raise ValueError("masks must have one entry (tensor or None) per field")
+    for i, m in enumerate(list(masks) + [shared_mask]):
+        if m is not None and not (m.is_cuda and m.dtype == torch.uint8 and m.is_contiguous() and m.numel() == n_gates):
+            raise ValueError(f"mask {i}: expected a contiguous cuda uint8 tensor of {n_gates} gates")
+    if csr.max_gate >= n_gates:
+        # the reference's fancy index (interpolate.py:74) raises the same way
+        raise IndexError(f"index {csr.max_gate} is out of bounds for axis 0 with size {n_gates}")
+    nz, ny, nx = (int(s) for s in geometry.grid_shape)
+    n_vox = nz * ny * nx
+    if out is None:
+        out = torch.empty((n_fields, nz, ny, nx), dtype=torch.float32, device=dev)
+    elif not (out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and out.numel() == n_fields * n_vox):
+        raise ValueError("out must be a contiguous cuda float32 tensor of shape [F, nz, ny, nx]")
+    fill = float(np.float32(fill_value))
+    with torch.cuda.device(dev):
+        stream = _native.stream_ptr()
+        for f0 in range(0, n_fields, _native.RG_MAX_FIELDS):
+            group = list(range(f0, min(n_fields, f0 + _native.RG_MAX_FIELDS)))
+            nf = len(group)
+            stride = _stride_for(nf)
+            packed = torch.empty(max(n_gates, 1) * stride, dtype=torch.float32, device=dev)
+            fptrs = (ctypes.c_void_p * nf)(*[_native.ptr(fields[i]) for i in group])
+            mptrs = (ctypes.c_void_p * nf)(*[_native.ptr(masks[i]) for i in group])
+            _native.check(lib.rg_pack_fields_f32(nf, fptrs, mptrs, _native.ptr(shared_mask), n_gates, stride,
+                                                 _native.ptr(packed), stream), "rg_pack_fields_f32")
+            out_view = out.view(n_fields, n_vox)[f0:f0 + nf]
+            _native.check(lib.rg_csr_apply_f32(_native.ptr(csr.indptr), int(csr.is_i64), _native.ptr(csr.gate_indices),
+                                               _native.ptr(csr.weights), n_vox, csr.n_pairs, _native.ptr(packed), nf,
+                                               stride, n_gates, fill, _native.ptr(out_view), stream),
+                          "rg_csr_apply_f32")
+    return out.view(n_fields, nz, ny, nx)
+
+
+def apply_geometry(geometry: GridGeometry, field_data: np.ndarray,
+                   additional_filters: Optional[List[GateFilter]] = None,
+                   fill_value: float = np.nan) -> np.ndarray:
+    """Weighted-mean gridding of one field (``radar_grid/interpolate.py:15-104``).
+
+    ``field_data``: flattened (masked) field, shape ``(n_gates,)``; masked gates and gates excluded by any of
+    ``additional_filters`` contribute to neither sum; voxels without a positive weight sum get ``fill_value``.
+    Returns a float32 array of shape ``geometry.grid_shape``.
+    """
+    filters = _coerce_filters(additional_filters)
+    values, mask = _host_field(field_data, filters)
+    torch = _native.torch_mod()
+    dev = _native.device()
+    f_t = torch.from_numpy(values).to(dev)
+    m_t = torch.from_numpy(mask).to(dev) if mask.any() else None
+    grid = grid_fields_device(geometry, [f_t], [m_t], fill_value=fill_value)
+    return grid[0].cpu().numpy().reshape(geometry.grid_shape)
+
+
+def apply_geometry_multi(geometry: GridGeometry, fields: Dict[str, np.ndarray],
+                         additional_filters: Optional[Dict[str, List[GateFilter]]] = None,
+                         fill_value: float = np.nan) -> Dict[str, np.ndarray]:
+    """Grid several fields (``radar_grid/interpolate.py:107-142``) -- one CSR pass for all of them.
+
+    ``additional_filters`` maps a field name to its filter list (a missing name means no filters).
+    """
+    if additional_filters is None:
+        additional_filters = {}
+    names = list(fields.keys())
+    if not names:
+        return {}
+    torch = _native.torch_mod()
+    dev = _native.device()
+    f_ts, m_ts = [], []
+    for name in names:
+        values, mask = _host_field(fields[name], _coerce_filters(additional_filters.get(name, None)))
+        f_ts.append(torch.from_numpy(values).to(dev))
+        m_ts.append(torch.from_numpy(mask).to(dev) if mask.any() else None)
+    grid = grid_fields_device(geometry, f_ts, m_ts, fill_value=fill_value).cpu().numpy()
+    return {name: grid[i].reshape(geometry.grid_shape) for i, name in enumerate(names)}

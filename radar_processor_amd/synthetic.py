@@ -220,3 +220,25 @@ CONFIGS = {
     "METRIC": dict(n_elev=12, n_az=360, n_gates=1000, grid_shape=(40, 2000, 2000),
                    grid_limits=((0.0, 15e3), (-240e3, 240e3), (-240e3, 240e3))),
 }
+
+
+def gate_coordinates_device(elev_deg, az_deg, ranges_m, device=None):
+    """Same as :func:`gate_coordinates` but computed in HBM by ``rg_antenna_to_cartesian_f32``
+    (csrc/rg_core.hip): returns three cuda float32 tensors ``[G]`` in ray-major order."""
+    from . import _native
+    torch = _native.torch_mod()
+    lib = _native.load_library()
+    dev = _native.device() if device is None else device
+    elev = np.asarray(elev_deg, dtype=np.float64)
+    az = np.asarray(az_deg, dtype=np.float64)
+    rng_m = np.ascontiguousarray(ranges_m, dtype=np.float64)
+    n_rays, n_gates = elev.shape[0] * az.shape[0], rng_m.shape[0]
+    el_ray = torch.from_numpy(np.repeat(elev, az.shape[0])).to(dev)
+    az_ray = torch.from_numpy(np.tile(az, elev.shape[0])).to(dev)
+    r_t = torch.from_numpy(rng_m).to(dev)
+    x, y, z = (torch.empty(n_rays * n_gates, dtype=torch.float32, device=dev) for _ in range(3))
+    with torch.cuda.device(dev):
+        _native.check(lib.rg_antenna_to_cartesian_f32(_native.ptr(r_t), n_gates, _native.ptr(az_ray), _native.ptr(el_ray),
+                                                      n_rays, _native.ptr(x), _native.ptr(y), _native.ptr(z),
+                                                      _native.stream_ptr()), "rg_antenna_to_cartesian_f32")
+    return x, y, z

@@ -1,0 +1,357 @@
+"""Parity tests proper: the HIP path (through the C ABI of libradargrid_hip.so) against
+
+ * the golden vectors produced by the reference (tests/golden), and
+ * the CPU oracle on the same seeded inputs,
+
+at sizes the oracle finishes in seconds.  Bars: neighbour sets / indices bit-exact; Barnes weights within 1
+float32 ulp; gridded values rtol 1e-5 with an absolute floor of 1e-5 * max|field| (the reference sums in
+float32, the GPU in float64 -- SURVEY.md §7 "Summation order"); products bit-exact.
+"""
+import numpy as np
+import pytest
+
+from conftest import (builder_kwargs, golden_names, grid_spec, load_golden, reference_indices, volume_for)
+from oracle import radar_grid_oracle as oracle
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def rg():
+    import radar_processor_amd as pkg
+    pkg.load_library()          # fails loudly if the HIP extension is missing
+    return pkg
+
+
+def _atol(data, mask):
+    good = np.isfinite(data) & ~mask
+    return RTOL * float(np.abs(data[good]).max()) if good.any() else 0.0
+
+
+def _assert_grid_close(got, want, atol):
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=atol, equal_nan=True)
+
+
+def _ref_geometry(rg, name, meta, ref):
+    shape, limits = grid_spec(meta)
+    return rg.GridGeometry(shape, limits, ref["indptr"], reference_indices(name, meta, ref), ref["weights"],
+                           toa=meta["toa"])
+
+
+# ------------------------------------------------------------------------------------------------
+# K1: csr_apply on the reference's own CSR
+# ------------------------------------------------------------------------------------------------
+class TestReferenceKnownAnswersOnGpu:
+    """The reference's unit-test cases (tests/test_radar_grid_interpolate.py) through apply_geometry."""
+
+    def _geom(self, rg, indptr, idx, w, shape=(1, 1, 1)):
+        return rg.GridGeometry(shape, ((0, 1000), (-500, 500), (-500, 500)), np.asarray(indptr, dtype=np.int32),
+                               np.asarray(idx, dtype=np.int32), np.asarray(w, dtype=np.float32), toa=2000.0)
+
+    def test_weighted_average(self, rg):
+        g = self._geom(rg, [0, 2], [0, 1], [0.3, 0.7])
+        out = rg.apply_geometry(g, np.ma.masked_invalid(np.ma.array([10.0, 20.0], dtype=np.float32)))
+        assert out.shape == (1, 1, 1) and out.dtype == np.float32
+        np.testing.assert_almost_equal(out[0, 0, 0], 17.0, decimal=5)
+
+    def test_single_point_three_gates(self, rg):
+        g = self._geom(rg, [0, 3], [0, 1, 2], [0.2, 0.5, 0.3])
+        out = rg.apply_geometry(g, np.ma.masked_invalid(np.ma.array([10.0, 20.0, 30.0], dtype=np.float32)))
+        np.testing.assert_almost_equal(out[0, 0, 0], 21.0, decimal=5)
+
+    def test_nan_and_inf_gates_are_excluded(self, rg):
+        g = self._geom(rg, [0, 3], [0, 1, 2], [0.3, 0.4, 0.3])
+        for bad in (np.nan, np.inf, -np.inf):
+            out = rg.apply_geometry(g, np.ma.masked_invalid(np.ma.array([10.0, bad, 30.0], dtype=np.float32)))
+            np.testing.assert_almost_equal(out[0, 0, 0], 20.0, decimal=5)
+
+    def test_fill_value_and_all_masked(self, rg):
+        g = self._geom(rg, [0, 0], [], [])
+        out = rg.apply_geometry(g, np.ma.masked_invalid(np.ma.array([10.0], dtype=np.float32)), fill_value=-9999.0)
+        assert out[0, 0, 0] == -9999.0
+        g = self._geom(rg, [0, 2], [0, 1], [0.5, 0.5])
+        out = rg.apply_geometry(g, np.ma.array([10.0, 20.0], mask=[True, True]))
+        assert np.isnan(out[0, 0, 0])
+
+    def test_empty_geometry(self, rg):
+        g = self._geom(rg, np.zeros(9), [], [], shape=(2, 2, 2))
+        out = rg.apply_geometry(g, np.ma.masked_invalid(np.ma.array([10.0], dtype=np.float32)))
+        assert out.shape == (2, 2, 2) and np.all(np.isnan(out))
+
+    def test_unmasked_input_and_filter_coercion(self, rg):
+        """F9: inputs without a full mask work; a bare GateFilter is accepted; junk raises ValueError."""
+        from types import SimpleNamespace
+        g = self._geom(rg, np.arange(0, 17, 2), np.arange(16), np.ones(16), shape=(2, 2, 2))
+        radar = SimpleNamespace(nrays=4, ngates=4, fields={"DBZH": {"data": np.full((4, 4), 10.0, dtype=np.float32)}})
+        radar.fields["DBZH"]["data"][0, :] = -999.0
+        gf = rg.GateFilter(radar).exclude_below("DBZH", 0.0)
+        plain = np.full(16, 10.0, dtype=np.float32)
+        out = rg.apply_geometry(g, plain, additional_filters=gf)
+        assert np.isnan(out.ravel()[0]) and np.isnan(out.ravel()[1]) and out.ravel()[2] == 10.0
+        with pytest.raises(ValueError, match="additional_filters must be a list"):
+            rg.apply_geometry(g, plain, additional_filters="nope")
+        multi = rg.apply_geometry_multi(g, {"A": np.ma.array(plain), "B": np.ma.array(plain * 2)},
+                                        additional_filters={"A": gf})
+        assert set(multi) == {"A", "B"} and np.isnan(multi["A"].ravel()[0]) and multi["B"].ravel()[0] == 20.0
+
+    def test_unmasked_nan_propagates(self, rg):
+        """A NaN that is NOT masked poisons its voxel, as NumPy arithmetic would (interpolate.py:78-82)."""
+        g = self._geom(rg, [0, 2, 4], [0, 1, 2, 3], [0.5, 0.5, 0.5, 0.5], shape=(1, 1, 2))
+        data = np.ma.array(np.array([1.0, np.nan, 3.0, 5.0], dtype=np.float32), mask=np.zeros(4, dtype=bool))
+        out = rg.apply_geometry(g, data)
+        assert np.isnan(out[0, 0, 0]) and out[0, 0, 1] == 4.0
+
+    def test_out_of_range_gate_index_raises(self, rg):
+        g = self._geom(rg, [0, 2], [0, 7], [0.5, 0.5])
+        with pytest.raises(IndexError):
+            rg.apply_geometry(g, np.ma.masked_invalid(np.ma.array([1.0, 2.0], dtype=np.float32)))
+
+
+@pytest.mark.parametrize("name", golden_names("g2_") + golden_names("g3_") + golden_names("g6_"))
+def test_apply_geometry_matches_reference(rg, name):
+    """HIP csr_apply fed the REFERENCE's CSR vs the reference's gridded outputs (plain / QC-filtered / fill)."""
+    meta, ref = load_golden(name)
+    vol = volume_for(meta)
+    geom = _ref_geometry(rg, name, meta, ref)
+    radar = vol.as_radar()
+    gf = None
+    if "qc" in meta:
+        gf = rg.GateFilter(radar).exclude_below(meta["qc"][0], meta["qc"][1])
+        assert int(gf.n_excluded()) == int(ref["qc_excluded_count"][0])
+    for fname in meta["fields"]:
+        fdata = rg.get_field_data(radar, fname)
+        data, mask = oracle.merge_masks(vol.fields[fname])
+        atol = _atol(data, mask)
+        _assert_grid_close(rg.apply_geometry(geom, fdata), ref[f"grid_{fname}"], atol)
+        if gf is not None:
+            _assert_grid_close(rg.apply_geometry(geom, fdata, additional_filters=[gf]), ref[f"grid_{fname}_qc"], atol)
+        if f"grid_{fname}_fill" in ref:
+            got = rg.apply_geometry(geom, fdata, fill_value=-9999.0)
+            want = ref[f"grid_{fname}_fill"]
+            np.testing.assert_array_equal(got == -9999.0, want == -9999.0)
+            np.testing.assert_allclose(got, want, rtol=RTOL, atol=atol)
+    if len(meta["fields"]) > 1:
+        # apply_geometry_multi: one fused CSR pass, per-field filters
+        fields = {f: rg.get_field_data(radar, f) for f in meta["fields"]}
+        filt = {meta["fields"][0]: [gf]} if gf is not None else None
+        multi = rg.apply_geometry_multi(geom, fields, additional_filters=filt)
+        for i, fname in enumerate(meta["fields"]):
+            data, mask = oracle.merge_masks(vol.fields[fname])
+            key = f"grid_{fname}_qc" if (gf is not None and i == 0) else f"grid_{fname}"
+            _assert_grid_close(multi[fname], ref[key], _atol(data, mask))
+
+
+@pytest.mark.parametrize("n_fields", [1, 2, 3, 4, 5, 8, 11])
+def test_fused_field_counts_vs_oracle(rg, n_fields):
+    """Every packed-field stride (1,2,4,8) and the >8-field chunking, random CSR with empty and long rows,
+    int32 and int64 row pointers, against the float64 oracle."""
+    import torch
+    rng = np.random.default_rng(100 + n_fields)
+    n_gates, shape = 5000, (3, 17, 29)
+    n_vox = int(np.prod(shape))
+    lengths = rng.integers(0, 40, size=n_vox)
+    lengths[rng.random(n_vox) < 0.3] = 0
+    lengths[rng.integers(0, n_vox, size=5)] = rng.integers(1500, 4000, size=5)   # rows longer than a tile
+    indptr = np.zeros(n_vox + 1, dtype=np.int64)
+    np.cumsum(lengths, out=indptr[1:])
+    idx = rng.integers(0, n_gates, size=int(indptr[-1])).astype(np.int32)
+    w = rng.random(idx.shape[0]).astype(np.float32) + 0.01
+    fields = [rng.normal(5.0, 20.0, size=n_gates).astype(np.float32) for _ in range(n_fields)]
+    masks = [rng.random(n_gates) < 0.2 for _ in range(n_fields)]
+    masks[0][:] = False
+    dev = torch.device("cuda", 0)
+    for ip_dtype in (np.int32, np.int64):
+        geom = rg.GridGeometry(shape, ((0, 1), (0, 1), (0, 1)), indptr.astype(ip_dtype), idx, w, toa=1.0)
+        if ip_dtype is np.int64:      # force the int64 kernel even though the pair count is small
+            csr = geom.device_csr(dev)
+            csr.indptr = csr.indptr.to(torch.int64)
+            csr.is_i64 = True
+        f_t = [torch.from_numpy(f).to(dev) for f in fields]
+        m_t = [torch.from_numpy(m.astype(np.uint8)).to(dev) if m.any() else None for m in masks]
+        out = rg.grid_fields_device(geom, f_t, m_t, fill_value=-1.0).cpu().numpy()
+        for i in range(n_fields):
+            want = oracle.csr_apply_f64(indptr, idx, w, fields[i], masks[i], shape, fill_value=-1.0)
+            np.testing.assert_allclose(out[i], want, rtol=2e-6, atol=2e-6 * 100.0)
+
+
+# ------------------------------------------------------------------------------------------------
+# geometry builder on the GPU
+# ------------------------------------------------------------------------------------------------
+GEOM_CASES = golden_names("g2_") + golden_names("g3_") + golden_names("g4_") + golden_names("g6_")
+
+
+@pytest.mark.parametrize("name", GEOM_CASES)
+def test_builder_matches_reference_csr(rg, name, tmp_path):
+    meta, ref = load_golden(name)
+    vol = volume_for(meta)
+    shape, limits = grid_spec(meta)
+    geom = rg.compute_grid_geometry(vol.gate_x, vol.gate_y, vol.gate_z, shape, limits, str(tmp_path),
+                                    **builder_kwargs(meta))
+    assert geom.radar_altitude == 0.0                      # reference quirk (compute.py:277-284)
+    assert geom.indptr.dtype == np.int32
+    ip, idx, w = oracle.canonical_rows(geom.indptr, geom.gate_indices, geom.weights)
+    r_ip, r_idx, r_w = oracle.canonical_rows(ref["indptr"], reference_indices(name, meta, ref), ref["weights"])
+    np.testing.assert_array_equal(ip, r_ip.astype(np.int64))       # same neighbour counts per voxel
+    np.testing.assert_array_equal(idx, r_idx)                      # same neighbour sets, bit-exact
+    if meta["weighting"] == "barnes2":
+        ulp = np.abs(w.view(np.int32).astype(np.int64) - r_w.view(np.int32).astype(np.int64))
+        assert ulp.max(initial=0) <= 1
+        assert (ulp > 0).mean() < 1e-3 if ulp.size else True
+    else:
+        np.testing.assert_array_equal(w, r_w)                      # exact rational arithmetic
+    # end to end: GPU-built geometry + GPU apply vs the reference's grid
+    fname = meta["fields"][0]
+    data, mask = oracle.merge_masks(vol.fields[fname])
+    got = rg.apply_geometry(geom, rg.get_field_data(vol.as_radar(), fname))
+    _assert_grid_close(got, ref[f"grid_{fname}"], _atol(data, mask))
+
+
+def test_builder_errors_and_npz_roundtrip(rg, tmp_path):
+    vol_x = np.zeros(4, dtype=np.float32)
+    with pytest.raises(ValueError, match="temp_dir does not exist"):
+        rg.compute_grid_geometry(vol_x, vol_x, vol_x, (1, 2, 2), ((0, 0), (-1, 1), (-1, 1)), "/nonexistent/dir")
+    with pytest.raises(ValueError, match="Unknown weighting function"):
+        rg.compute_grid_geometry(vol_x, vol_x, vol_x, (1, 2, 2), ((0, 0), (-1, 1), (-1, 1)), str(tmp_path),
+                                 weighting="gaussian")
+    geom = rg.compute_grid_geometry(np.array([10.0, -20.0, 300.0], dtype=np.float32),
+                                    np.array([5.0, 0.0, -100.0], dtype=np.float32),
+                                    np.array([0.0, 50.0, 20.0], dtype=np.float32),
+                                    (2, 3, 3), ((0.0, 100.0), (-200.0, 200.0), (-200.0, 200.0)), str(tmp_path))
+    path = str(tmp_path / "g.npz")
+    rg.save_geometry(geom, path)
+    back = rg.load_geometry(path)
+    assert back == geom and back.n_pairs() == geom.n_pairs() > 0
+
+
+# ------------------------------------------------------------------------------------------------
+# K3 / K4 products
+# ------------------------------------------------------------------------------------------------
+def _check_products(rg, prefix, grid, geom, ref):
+    eq = np.testing.assert_array_equal
+    eq(rg.constant_altitude_ppi(grid, geom, 4000.0, "linear"), ref[f"{prefix}_cappi4000_linear"])
+    eq(rg.constant_altitude_ppi(grid, geom, 4000.0, "nearest"), ref[f"{prefix}_cappi4000_nearest"])
+    eq(rg.constant_altitude_ppi(grid, geom, 2500.0, "linear"), ref[f"{prefix}_cappi2500_linear"])
+    eq(rg.constant_altitude_ppi(grid, geom, 99000.0, "linear"), ref[f"{prefix}_cappi_above"])
+    eq(rg.column_max(grid), ref[f"{prefix}_colmax"])
+    eq(rg.column_max(grid, z_min_alt=1000, z_max_alt=8000, geometry=geom), ref[f"{prefix}_colmax_alt"])
+    eq(rg.column_max(grid, z_min_idx=2, z_max_idx=6), ref[f"{prefix}_colmax_idx"])
+    eq(rg.column_min(grid), ref[f"{prefix}_colmin"])
+    eq(rg.column_mean(grid), ref[f"{prefix}_colmean"])
+    eq(rg.column_mean(grid, z_min_alt=1000, z_max_alt=8000, geometry=geom), ref[f"{prefix}_colmean_alt"])
+    cmax, arg = rg.column_argmax(grid)
+    eq(cmax, ref[f"{prefix}_colmax"])
+    eq(arg, oracle.column_argmax(grid, 0, grid.shape[0] - 1))      # bit-exact argmax contract
+    assert arg.dtype == np.int32
+
+
+@pytest.mark.parametrize("name", golden_names("g5_"))
+def test_products_match_reference(rg, name):
+    meta, ref = load_golden(name)
+    grid = ref["grid"]
+    geom = rg.GridGeometry(grid.shape, (tuple(meta["z_limits"]), (-1e4, 1e4), (-1.4e4, 1.4e4)),
+                           np.zeros(grid.size + 1, dtype=np.int32), np.zeros(0, dtype=np.int32),
+                           np.zeros(0, dtype=np.float32), toa=17000.0)
+    _check_products(rg, "P", grid, geom, ref)
+    # views, not copies, on exact / nearest levels (products.py:378,386)
+    assert np.shares_memory(rg.constant_altitude_ppi(grid, geom, 4000.0, "nearest"), grid)
+    with pytest.raises(ValueError, match="Unknown interpolation method"):
+        rg.constant_altitude_ppi(grid, geom, 4000.0, "cubic")
+    with pytest.raises(ValueError, match="geometry is required"):
+        rg.column_max(grid, z_min_alt=1000.0)
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names("g3_") if n.endswith("barnes2")])
+def test_products_on_gridded_windows(rg, name):
+    meta, ref = load_golden(name)
+    _check_products(rg, "DBZH", ref["grid_DBZH"], _ref_geometry(rg, name, meta, ref), ref)
+
+
+@pytest.mark.parametrize("shape", [(20, 64, 96), (9, 315, 315), (40, 1000, 1200), (3, 7, 5)])
+def test_column_products_vs_numpy_all_paths(rg, shape):
+    """Vector / scalar and level-split / sequential kernel variants; device tensors stay on the device."""
+    import torch
+    rng = np.random.default_rng(7)
+    grid = rng.normal(10.0, 15.0, size=shape).astype(np.float32)
+    grid[rng.random(shape) < 0.3] = np.nan
+    grid[:, : max(1, shape[1] // 8), :] = np.nan
+    grid[1:3, -2:, :] = np.float32(33.25)
+    lo, hi = 0, shape[0] - 1
+    eq = np.testing.assert_array_equal
+    eq(rg.column_max(grid), oracle.column_max(grid, lo, hi))
+    eq(rg.column_min(grid), oracle.column_min(grid, lo, hi))
+    eq(rg.column_mean(grid), oracle.column_mean(grid, lo, hi))
+    t = torch.from_numpy(grid).cuda()
+    cmax, arg = rg.column_argmax(t)
+    assert cmax.is_cuda and arg.is_cuda
+    eq(cmax.cpu().numpy(), oracle.column_max(grid, lo, hi))
+    eq(arg.cpu().numpy(), oracle.column_argmax(grid, lo, hi))
+    if shape[0] > 4:
+        eq(rg.column_max(grid, z_min_idx=1, z_max_idx=shape[0] - 2), oracle.column_max(grid, 1, shape[0] - 2))
+
+
+# ------------------------------------------------------------------------------------------------
+# a1 / a3 small kernels
+# ------------------------------------------------------------------------------------------------
+def test_device_gate_predicates(rg):
+    import torch
+    rng = np.random.default_rng(3)
+    data = rng.normal(0.5, 0.4, size=100003).astype(np.float32)
+    data[::17] = np.nan
+    data[5::1001] = np.inf
+    t = torch.from_numpy(data).cuda()
+    for op, a, b in (("below", 0.8, 0), ("above", 0.9, 0), ("between", 0.2, 0.6), ("outside", 0.1, 0.9),
+                     ("equal", 0.5, 0.05), ("invalid", 0, 0)):
+        got = rg.device_gate_mask(t, op, a, b).cpu().numpy().astype(bool)
+        np.testing.assert_array_equal(got, oracle.gate_mask(op, data, np.float32(a), np.float32(b)))
+    # OR-accumulation into an existing mask
+    m = rg.device_gate_mask(t, "below", 0.0)
+    m = rg.device_gate_mask(t, "invalid", mask=m).cpu().numpy().astype(bool)
+    np.testing.assert_array_equal(m, (data < 0) | ~np.isfinite(data))
+
+
+def test_antenna_transform_kernel(rg):
+    from radar_processor_amd import synthetic
+    elev, az, rng_m = synthetic.sweep_geometry(12, 90, 333)
+    x, y, z = synthetic.gate_coordinates_device(elev, az, rng_m)
+    ex, ey, ez = synthetic.gate_coordinates(elev, az, rng_m)
+    for got, want in ((x, ex), (y, ey), (z, ez)):
+        got = got.cpu().numpy()
+        ulp = np.abs(got.view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64))
+        # float64 sin/cos/asin of two libms rounded to float32: identical except rare 1-ulp double roundings
+        close_to_zero = np.abs(want) < 1e-3
+        assert ulp[~close_to_zero].max() <= 1
+        np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------------
+# K2: fused on-the-fly gridder (no CSR)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", golden_names("g2_c1_mid") + golden_names("g3_c2_r0") + golden_names("g3_c2_r150")
+                         + golden_names("g4_c4_r030") + golden_names("g6_"))
+def test_fused_roi_grid_matches_reference(rg, name):
+    import torch
+    meta, ref = load_golden(name)
+    vol = volume_for(meta)
+    shape, limits = grid_spec(meta)
+    kw = builder_kwargs(meta)
+    weighting = kw.pop("weighting")
+    search = rg.RoiSearch(vol.gate_x, vol.gate_y, vol.gate_z, shape, limits, **kw)
+    names = list(meta["fields"])
+    f_t, m_t = [], []
+    for fname in names:
+        data, mask = oracle.merge_masks(vol.fields[fname])
+        f_t.append(torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).to(search.dev))
+        m_t.append(torch.from_numpy(mask.astype(np.uint8)).to(search.dev))
+    out = rg.roi_grid_fields_device(search, f_t, m_t, weighting=weighting).cpu().numpy()
+    for i, fname in enumerate(names):
+        data, mask = oracle.merge_masks(vol.fields[fname])
+        _assert_grid_close(out[i], ref[f"grid_{fname}"], _atol(data, mask))
+    if "qc" in meta:
+        qc = rg.device_gate_mask(f_t[names.index(meta["qc"][0])], "below", meta["qc"][1])
+        out = rg.roi_grid_fields_device(search, f_t, m_t, shared_mask=qc, weighting=weighting).cpu().numpy()
+        for i, fname in enumerate(names):
+            data, mask = oracle.merge_masks(vol.fields[fname])
+            _assert_grid_close(out[i], ref[f"grid_{fname}_qc"], _atol(data, mask))

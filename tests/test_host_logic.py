@@ -1,0 +1,259 @@
+"""CPU-side checks (no GPU needed): the geometry container and its .npz format, GateFilter predicates, the
+reference's error behaviour, the C-ABI library (loads, exports every symbol include/radargrid_hip.h declares),
+and that the product path refuses to run without a HIP device instead of falling back to the CPU.
+
+Modelled on the reference's tests/test_radar_grid_geometry.py and tests/test_radar_grid_filters.py.
+"""
+import ctypes
+import os
+import re
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+import radar_processor_amd as rg
+from conftest import REPO
+from oracle import radar_grid_oracle as oracle
+from radar_processor_amd import _native
+
+
+def _no_gpu():
+    try:
+        import torch
+        return not torch.cuda.is_available()
+    except Exception:
+        return True
+
+
+@pytest.fixture
+def geometry():
+    nz, ny, nx = 4, 5, 6
+    n = nz * ny * nx
+    return rg.GridGeometry(
+        grid_shape=(nz, ny, nx),
+        grid_limits=((0.0, 3000.0), (-2000.0, 2000.0), (-2500.0, 2500.0)),
+        indptr=np.arange(0, 2 * n + 1, 2, dtype=np.int32),
+        gate_indices=np.arange(2 * n, dtype=np.int32),
+        weights=np.full(2 * n, 0.5, dtype=np.float32),
+        toa=12000.0, radar_altitude=150.0)
+
+
+class TestGridGeometry:           # reference: tests/test_radar_grid_geometry.py
+    def test_counters(self, geometry):
+        assert geometry.n_grid_points() == 120
+        assert geometry.n_pairs() == 240
+        assert geometry.avg_neighbors() == 2.0
+        assert geometry.memory_usage_mb() == pytest.approx((121 * 4 + 240 * 4 + 240 * 4) / 1e6)
+        assert not geometry.is_device_resident
+
+    def test_z_levels(self, geometry):
+        np.testing.assert_array_equal(geometry.z_levels(), np.linspace(0.0, 3000.0, 4))
+        np.testing.assert_array_equal(geometry.z_levels_absolute(), np.linspace(0.0, 3000.0, 4) + 150.0)
+
+    def test_default_radar_altitude_and_repr(self, geometry):
+        g = rg.GridGeometry((1, 1, 1), ((0, 1), (0, 1), (0, 1)), np.zeros(2, dtype=np.int32),
+                            np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.float32), toa=1.0)
+        assert g.radar_altitude == 0.0
+        text = repr(geometry)
+        assert text.startswith("GridGeometry(") and "n_pairs=240" in text and "avg_neighbors=2.0" in text
+        assert "toa=12000.0m" in text and "radar_altitude=150.0m" in text
+
+    def test_npz_roundtrip_and_keys(self, geometry, tmp_path):
+        path = str(tmp_path / "geom.npz")
+        rg.save_geometry(geometry, path)
+        with np.load(path) as z:
+            assert sorted(z.files) == sorted(["grid_shape", "grid_limits_z", "grid_limits_y", "grid_limits_x", "indptr",
+                                              "gate_indices", "weights", "toa", "radar_altitude"])
+        back = rg.load_geometry(path)
+        assert back == geometry
+        assert back.grid_shape == (4, 5, 6) and back.toa == 12000.0 and back.radar_altitude == 150.0
+        assert back.grid_limits == geometry.grid_limits
+
+    def test_load_without_optional_keys(self, tmp_path):
+        """Old files lack toa / radar_altitude (geometry.py:146-147)."""
+        path = str(tmp_path / "old.npz")
+        np.savez_compressed(path, grid_shape=np.array([1, 1, 2]), grid_limits_z=np.array([0.0, 0.0]),
+                            grid_limits_y=np.array([0.0, 0.0]), grid_limits_x=np.array([0.0, 1.0]),
+                            indptr=np.array([0, 1, 2], dtype=np.int32), gate_indices=np.array([0, 1], dtype=np.int32),
+                            weights=np.ones(2, dtype=np.float32))
+        g = rg.load_geometry(path)
+        assert g.toa == np.inf and g.radar_altitude == 0.0 and g.n_pairs() == 2
+
+
+@pytest.fixture
+def radar():
+    rng = np.random.default_rng(0)
+    nrays, ngates = 100, 500
+    dbz = rng.normal(20, 15, size=(nrays, ngates)).astype(np.float32)
+    dbz[3, 10:20] = np.nan
+    dbz[4, 5] = np.inf
+    rho = rng.uniform(0.5, 1.0, size=(nrays, ngates)).astype(np.float32)
+    r = SimpleNamespace(nrays=nrays, ngates=ngates)
+    r.fields = {"DBZH": {"data": np.ma.array(dbz, mask=dbz < -10)}, "RHOHV": {"data": rho}}
+    r.gate_altitude = {"data": rng.uniform(0, 15000, size=(nrays, ngates))}
+    r.range = {"data": np.arange(ngates) * 250.0}
+    r.elevation = {"data": np.repeat(np.array([0.5, 1.5, 3.0, 10.0, 30.0]), 20)}
+    return r
+
+
+class TestGateFilter:             # reference: tests/test_radar_grid_filters.py
+    def test_starts_empty(self, radar):
+        gf = rg.GateFilter(radar)
+        assert gf.n_gates == 50000 and gf.n_excluded() == 0 and gf.n_included() == 50000
+        assert gf.gate_included.all()
+
+    @pytest.mark.parametrize("method,args,op", [
+        ("exclude_below", (5.0,), ("below", 5.0, 0)), ("exclude_above", (40.0,), ("above", 40.0, 0)),
+        ("exclude_between", (0.0, 10.0), ("between", 0.0, 10.0)), ("exclude_outside", (0.0, 30.0), ("outside", 0.0, 30.0)),
+        ("exclude_equal", (20.0, 0.5), ("equal", 20.0, 0.5)), ("exclude_invalid", (), ("invalid", 0, 0))])
+    def test_threshold_predicates(self, radar, method, args, op):
+        gf = getattr(rg.GateFilter(radar), method)("DBZH", *args)
+        raw = np.ma.getdata(radar.fields["DBZH"]["data"]).ravel()
+        np.testing.assert_array_equal(gf.gate_excluded, oracle.gate_mask(op[0], raw, op[1], op[2]))
+
+    def test_nan_not_excluded_by_threshold(self, radar):
+        gf = rg.GateFilter(radar).exclude_below("DBZH", 1e9)
+        assert not gf.gate_excluded[3 * 500 + 10]           # NaN < x is False (filters.py:134)
+
+    def test_missing_field_is_a_warning_noop(self, radar, caplog):
+        with caplog.at_level("WARNING", logger="radar_grid.filters"):
+            gf = rg.GateFilter(radar).exclude_below("KDP", 1.0)
+        assert gf.n_excluded() == 0 and "not found in radar" in caplog.text
+
+    def test_masked_and_all_invalid(self, radar):
+        m = np.ma.getmaskarray(radar.fields["DBZH"]["data"]).ravel()
+        np.testing.assert_array_equal(rg.GateFilter(radar).exclude_masked("DBZH").gate_excluded, m)
+        inv = np.ma.getmaskarray(np.ma.masked_invalid(radar.fields["DBZH"]["data"])).ravel()
+        np.testing.assert_array_equal(rg.GateFilter(radar).exclude_all_invalid("DBZH").gate_excluded, inv)
+        assert rg.GateFilter(radar).exclude_masked("RHOHV").n_excluded() == 0   # plain ndarray: nothing masked
+
+    def test_geometric_predicates(self, radar):
+        alt = radar.gate_altitude["data"].ravel()
+        np.testing.assert_array_equal(rg.GateFilter(radar).exclude_below_altitude(2000.0).gate_excluded, alt < 2000.0)
+        np.testing.assert_array_equal(rg.GateFilter(radar).exclude_above_altitude(9000.0).gate_excluded, alt > 9000.0)
+        rng2d = np.broadcast_to(radar.range["data"], (100, 500)).ravel()
+        np.testing.assert_array_equal(rg.GateFilter(radar).exclude_below_range(5000.0).gate_excluded, rng2d < 5000.0)
+        np.testing.assert_array_equal(rg.GateFilter(radar).exclude_above_range(100000.0).gate_excluded, rng2d > 100000.0)
+        el = np.repeat(radar.elevation["data"], 500)
+        np.testing.assert_array_equal(rg.GateFilter(radar).exclude_below_elevation_angle(2.0).gate_excluded, el < 2.0)
+        np.testing.assert_array_equal(rg.GateFilter(radar).exclude_above_elevation_angle(20.0).gate_excluded, el > 20.0)
+        np.testing.assert_array_equal(rg.GateFilter(radar).exclude_outside_elevation_range(1.0, 20.0).gate_excluded,
+                                      (el < 1.0) | (el > 20.0))
+
+    def test_chaining_copy_reset_custom(self, radar):
+        gf = rg.GateFilter(radar).exclude_below("DBZH", 0.0).exclude_below("RHOHV", 0.8)
+        assert len(gf._filter_history) == 2 and "Filters applied (2)" in gf.summary()
+        dup = gf.copy()
+        dup.exclude_all()
+        assert dup.n_excluded() == 50000 and gf.n_excluded() < 50000
+        assert gf.reset().n_excluded() == 0 and gf.include_all() is gf
+        with pytest.raises(ValueError, match="doesn't match n_gates"):
+            gf.exclude_where(np.zeros(7, dtype=bool))
+        gf.exclude_where(np.ones((100, 500), dtype=bool), "everything")
+        assert gf.n_excluded() == 50000
+        gf2 = rg.GateFilter(radar).exclude_by_function("RHOHV", lambda x: x < 0.75, "low rho")
+        assert "RHOHV: low rho" in gf2._filter_history[0]
+
+    def test_create_mask_from_filter(self, radar):
+        gf = rg.GateFilter(radar).exclude_below("RHOHV", 0.8)
+        data, mask = rg.create_mask_from_filter(radar, "DBZH", gf)
+        assert data.dtype == np.float32 and data.shape == (50000,)
+        inv = np.ma.getmaskarray(np.ma.masked_invalid(radar.fields["DBZH"]["data"])).ravel()
+        np.testing.assert_array_equal(mask, inv | gf.gate_excluded)
+        _, mask0 = rg.create_mask_from_filter(radar, "DBZH")
+        np.testing.assert_array_equal(mask0, inv)
+
+
+class TestAdaptors:
+    def test_field_and_coordinates(self):
+        from radar_processor_amd import synthetic
+        vol = synthetic.make_volume(n_elev=2, n_az=8, n_gates=16, seed=3, fields=("DBZH",))
+        radar = vol.as_radar()
+        gx, gy, gz = rg.get_gate_coordinates(radar)
+        assert gx.dtype == np.float32 and gx.shape == (2 * 8 * 16,)
+        np.testing.assert_array_equal(gz, vol.gate_z)
+        f = rg.get_field_data(radar, "DBZH")
+        assert isinstance(f, np.ma.MaskedArray) and f.dtype == np.float32 and f.shape == gx.shape
+        assert rg.get_available_fields(radar) == ["DBZH"]
+        info = rg.get_radar_info(radar)
+        assert info["nrays"] == 16 and info["ngates"] == 16 and info["total_gates"] == 256 and info["volume_nr"] == "03"
+
+
+class TestErrorBehaviourBeforeTheGpu:
+    """Argument errors are raised by host code, identically with or without a device."""
+
+    def test_bad_filter_type(self, geometry):
+        with pytest.raises(ValueError, match="additional_filters must be a list of GateFilter objects"):
+            rg.apply_geometry(geometry, np.ma.zeros(240), additional_filters=42)
+
+    def test_builder_validation(self, tmp_path):
+        z = np.zeros(3, dtype=np.float32)
+        with pytest.raises(ValueError, match="temp_dir does not exist"):
+            rg.compute_grid_geometry(z, z, z, (1, 1, 1), ((0, 0), (0, 0), (0, 0)), str(tmp_path / "missing"))
+        with pytest.raises(ValueError, match="Unknown weighting function: idw"):
+            rg.compute_grid_geometry(z, z, z, (1, 1, 1), ((0, 0), (0, 0), (0, 0)), str(tmp_path), weighting="idw")
+
+    def test_cappi_scalar_paths_need_no_gpu(self, geometry, caplog):
+        grid = np.arange(120, dtype=np.float32).reshape(4, 5, 6)
+        with caplog.at_level("WARNING", logger="radar_grid.products"):
+            out = rg.constant_altitude_ppi(grid, geometry, 99999.0)
+        assert out.dtype == np.float32 and np.all(np.isnan(out)) and "outside grid range" in caplog.text
+        level = rg.constant_altitude_ppi(grid, geometry, 1000.0)           # exact level 1: a view
+        assert np.shares_memory(level, grid) and np.array_equal(level, grid[1])
+        assert np.array_equal(rg.constant_altitude_ppi(grid, geometry, 1400.0, "nearest"), grid[1])
+        with pytest.raises(ValueError, match="Unknown interpolation method: cubic"):
+            rg.constant_altitude_ppi(grid, geometry, 1400.0, "cubic")
+        with pytest.raises(ValueError, match="geometry is required when using altitude-based limits"):
+            rg.column_max(grid, z_min_alt=10.0)
+
+
+class TestNativeLibrary:
+    def test_header_symbols_are_exported(self):
+        """Every function declared in include/radargrid_hip.h is exported by the built library, and the
+        ctypes table binds exactly that set."""
+        header = open(os.path.join(REPO, "include", "radargrid_hip.h")).read()
+        declared = set(re.findall(r"^(?:int|int64_t|const char\*)\s+(rg_\w+)\s*\(", header, flags=re.M))
+        assert len(declared) >= 15
+        assert os.path.exists(_native.LIB_PATH), "build with `python -m radar_processor_amd.build`"
+        lib = ctypes.CDLL(_native.LIB_PATH)
+        for name in sorted(declared):
+            assert hasattr(lib, name), f"{name} declared in the header but not exported"
+        assert declared == set(_native.SIGNATURES)
+
+    def test_version_and_constants(self):
+        lib = rg.load_library(require_device=False)
+        assert lib.rg_version() == 100
+        header = open(os.path.join(REPO, "include", "radargrid_hip.h")).read()
+        assert f"0x{_native.RG_EXCLUDED_BITS:08X}" in header.upper().replace("0X", "0x")
+        assert np.isnan(np.array([_native.RG_EXCLUDED_BITS], dtype=np.uint32).view(np.float32)[0])
+
+    def test_argument_validation_without_compute(self):
+        """Entry points reject bad arguments before touching the device."""
+        lib = rg.load_library(require_device=False)
+        assert lib.rg_csr_apply_f32(None, 0, None, None, 4, 0, None, 1, 1, 0, 0.0, None, None) == _native.RG_EINVAL
+        assert b"null" in lib.rg_last_error()
+        assert lib.rg_csr_apply_f32(1 << 12, 0, None, None, 4, 0, None, 9, 8, 0, 0.0, 1 << 12, None) == _native.RG_EUNSUPPORTED
+        assert lib.rg_column_reduce_f32(1 << 12, 4, 16, 0, 7, 0, 1 << 12, None, None) == _native.RG_EINVAL
+        assert lib.rg_gate_mask_f32(1 << 12, 8, 99, 0.0, 0.0, 1 << 12, None) == _native.RG_EINVAL
+        assert lib.rg_geom_bin_workspace_bytes(-1, 4, 4) == _native.RG_EINVAL
+        assert lib.rg_geom_bin_workspace_bytes(1000, 4, 4) > 4 * 1000 * 4
+
+    @pytest.mark.skipif(not _no_gpu(), reason="only meaningful on a box without a GPU")
+    def test_no_cpu_fallback(self, geometry):
+        """Without a HIP device the product path raises instead of computing on the CPU."""
+        field = np.ma.masked_invalid(np.arange(240, dtype=np.float32))
+        with pytest.raises(rg.NativeUnavailable):
+            rg.apply_geometry(geometry, field)
+        with pytest.raises(rg.NativeUnavailable):
+            rg.column_max(np.zeros((4, 5, 6), dtype=np.float32))
+        with pytest.raises(rg.NativeUnavailable):
+            rg.constant_altitude_ppi(np.zeros((4, 5, 6), dtype=np.float32), geometry, 1500.0)
+
+    def test_product_package_never_imports_the_oracle(self):
+        pkg_dir = os.path.dirname(rg.__file__)
+        for root, _, files in os.walk(pkg_dir):
+            for f in files:
+                if f.endswith(".py"):
+                    text = open(os.path.join(root, f)).read()
+                    assert not re.search(r"^\s*(from|import)\s+oracle", text, flags=re.M), f"{f} imports the oracle"
