@@ -59,6 +59,71 @@ def _host_field(field_data, filters: Sequence[GateFilter]):
     return values, np.ascontiguousarray(mask, dtype=np.uint8)
 
 
+class CsrGridder:
+    """Persistent device buffers + launches for gridding field groups of a fixed size through one geometry.
+
+    Holds the packed-field staging buffer so that repeated volumes cost no allocation, and exposes the two
+    stages separately (``pack`` = mask fold + interleave, ``apply`` = the CSR pass) so that callers can time
+    or graph-capture them.  All launches go to torch's current stream.
+    """
+
+    def __init__(self, geometry: GridGeometry, n_gates: int, n_fields: int, device=None):
+        torch = _native.torch_mod()
+        self.lib = _native.load_library()
+        if not 1 <= n_fields <= _native.RG_MAX_FIELDS:
+            raise ValueError(f"n_fields must be in 1..{_native.RG_MAX_FIELDS}")
+        self.dev = _native.device() if device is None else device
+        self.csr = geometry.device_csr(self.dev)
+        self.n_gates = int(n_gates)
+        self.n_fields = int(n_fields)
+        self.stride = _stride_for(n_fields)
+        self.grid_shape = tuple(int(s) for s in geometry.grid_shape)
+        self.n_vox = int(np.prod(self.grid_shape))
+        if self.csr.max_gate >= self.n_gates:
+            # the reference's fancy index (interpolate.py:74) raises the same way
+            raise IndexError(f"index {self.csr.max_gate} is out of bounds for axis 0 with size {self.n_gates}")
+        self.packed = torch.empty(max(self.n_gates, 1) * self.stride, dtype=torch.float32, device=self.dev)
+
+    def _check_fields(self, fields, masks, shared_mask):
+        torch = _native.torch_mod()
+        if len(fields) != self.n_fields:
+            raise ValueError(f"expected {self.n_fields} fields, got {len(fields)}")
+        for i, f in enumerate(fields):
+            if not (f.is_cuda and f.dtype == torch.float32 and f.is_contiguous() and f.numel() == self.n_gates):
+                raise ValueError(f"field {i}: expected a contiguous cuda float32 tensor of {self.n_gates} gates")
+        if len(masks) != self.n_fields:
+            raise ValueError("masks must have one entry (tensor or None) per field")
+        for i, m in enumerate(list(masks) + [shared_mask]):
+            if m is not None and not (m.is_cuda and m.dtype == torch.uint8 and m.is_contiguous()
+                                      and m.numel() == self.n_gates):
+                raise ValueError(f"mask {i}: expected a contiguous cuda uint8 tensor of {self.n_gates} gates")
+
+    def pack(self, fields: Sequence, masks: Optional[Sequence] = None, shared_mask=None) -> None:
+        """``rg_pack_fields_f32``: fold every field's exclusion mask into its values, interleave gate-major."""
+        masks = [None] * self.n_fields if masks is None else list(masks)
+        self._check_fields(fields, masks, shared_mask)
+        nf = self.n_fields
+        fptrs = (ctypes.c_void_p * nf)(*[_native.ptr(f) for f in fields])
+        mptrs = (ctypes.c_void_p * nf)(*[_native.ptr(m) for m in masks])
+        _native.check(self.lib.rg_pack_fields_f32(nf, fptrs, mptrs, _native.ptr(shared_mask), self.n_gates, self.stride,
+                                                  _native.ptr(self.packed), _native.stream_ptr()), "rg_pack_fields_f32")
+
+    def apply(self, out, fill_value: float = np.nan) -> None:
+        """``rg_csr_apply_f32``: one pass over the CSR for all packed fields -> ``out[F, n_vox]``."""
+        csr = self.csr
+        _native.check(self.lib.rg_csr_apply_f32(
+            _native.ptr(csr.indptr), int(csr.is_i64), _native.ptr(csr.gate_indices), _native.ptr(csr.weights),
+            self.n_vox, csr.n_pairs, _native.ptr(self.packed), self.n_fields, self.stride, self.n_gates,
+            float(np.float32(fill_value)), _native.ptr(out), _native.stream_ptr()), "rg_csr_apply_f32")
+
+    def algorithmic_bytes(self) -> int:
+        """Bytes one ``apply`` launch must move: index + weight per pair, the row pointers,
+        each field's values + mask once, each output grid once."""
+        csr = self.csr
+        ip = 8 if csr.is_i64 else 4
+        return 8 * csr.n_pairs + ip * (self.n_vox + 1) + self.n_fields * (5 * self.n_gates + 4 * self.n_vox)
+
+
 def grid_fields_device(geometry: GridGeometry, fields: Sequence, masks: Optional[Sequence] = None,
                        shared_mask=None, fill_value: float = np.nan, out=None):
     """Grid ``len(fields)`` device-resident fields with one CSR pass per group of up to 8.
@@ -73,51 +138,29 @@ def grid_fields_device(geometry: GridGeometry, fields: Sequence, masks: Optional
     Returns the ``[F, nz, ny, nx]`` float32 tensor (device).
     """
     torch = _native.torch_mod()
-    lib = _native.load_library()
     n_fields = len(fields)
     if n_fields == 0:
         raise ValueError("no fields to grid")
     dev = fields[0].device
     if dev.type != "cuda":
         raise _native.NativeUnavailable("grid_fields_device needs device-resident (cuda) tensors")
-    csr = geometry.device_csr(dev)
-    n_gates = int(fields[0].numel())
-    for i, f in enumerate(fields):
-        if not (f.is_cuda and f.dtype == torch.float32 and f.is_contiguous() and f.numel() == n_gates):
-            raise ValueError(f"field {i}: expected a contiguous cuda float32 tensor of {n_gates} gates")
     if masks is None:
         masks = [None] * n_fields
     if len(masks) != n_fields:
         raise ValueError("masks must have one entry (tensor or None) per field")
-    for i, m in enumerate(list(masks) + [shared_mask]):
-        if m is not None and not (m.is_cuda and m.dtype == torch.uint8 and m.is_contiguous() and m.numel() == n_gates):
-            raise ValueError(f"mask {i}: expected a contiguous cuda uint8 tensor of {n_gates} gates")
-    if csr.max_gate >= n_gates:
-        # the reference's fancy index (interpolate.py:74) raises the same way
-        raise IndexError(f"index {csr.max_gate} is out of bounds for axis 0 with size {n_gates}")
     nz, ny, nx = (int(s) for s in geometry.grid_shape)
     n_vox = nz * ny * nx
     if out is None:
         out = torch.empty((n_fields, nz, ny, nx), dtype=torch.float32, device=dev)
     elif not (out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and out.numel() == n_fields * n_vox):
         raise ValueError("out must be a contiguous cuda float32 tensor of shape [F, nz, ny, nx]")
-    fill = float(np.float32(fill_value))
+    n_gates = int(fields[0].numel())
     with torch.cuda.device(dev):
-        stream = _native.stream_ptr()
         for f0 in range(0, n_fields, _native.RG_MAX_FIELDS):
-            group = list(range(f0, min(n_fields, f0 + _native.RG_MAX_FIELDS)))
-            nf = len(group)
-            stride = _stride_for(nf)
-            packed = torch.empty(max(n_gates, 1) * stride, dtype=torch.float32, device=dev)
-            fptrs = (ctypes.c_void_p * nf)(*[_native.ptr(fields[i]) for i in group])
-            mptrs = (ctypes.c_void_p * nf)(*[_native.ptr(masks[i]) for i in group])
-            _native.check(lib.rg_pack_fields_f32(nf, fptrs, mptrs, _native.ptr(shared_mask), n_gates, stride,
-                                                 _native.ptr(packed), stream), "rg_pack_fields_f32")
-            out_view = out.view(n_fields, n_vox)[f0:f0 + nf]
-            _native.check(lib.rg_csr_apply_f32(_native.ptr(csr.indptr), int(csr.is_i64), _native.ptr(csr.gate_indices),
-                                               _native.ptr(csr.weights), n_vox, csr.n_pairs, _native.ptr(packed), nf,
-                                               stride, n_gates, fill, _native.ptr(out_view), stream),
-                          "rg_csr_apply_f32")
+            f1 = min(n_fields, f0 + _native.RG_MAX_FIELDS)
+            gridder = CsrGridder(geometry, n_gates, f1 - f0, device=dev)
+            gridder.pack(fields[f0:f1], masks[f0:f1], shared_mask)
+            gridder.apply(out.view(n_fields, n_vox)[f0:f1], fill_value)
     return out.view(n_fields, nz, ny, nx)
 
 
