@@ -48,6 +48,8 @@ SIGNATURES = {
                                      c_void_p, c_void_p]),
     "rg_csr_apply_f32": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int32,
                                    c_int32, c_int64, c_float, c_void_p, c_void_p]),
+    "rg_csr_apply_f32_ex": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int32,
+                                      c_int32, c_int64, c_float, c_void_p, c_int32, c_void_p]),
     "rg_column_reduce_f32": (c_int32, [c_void_p, c_int32, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                        c_void_p]),
     "rg_cappi_lerp_f32": (c_int32, [c_void_p, c_int64, c_int32, c_float, c_float, c_void_p, c_void_p]),
