@@ -196,6 +196,178 @@ __global__ __launch_bounds__(rg::kBlock) void csr_apply_kernel(
   }
 }
 
+// XCD placement of the 64-row chunks (speed only, never correctness):
+//   kXcdNone   workgroup b -> logical block b: neighbouring blocks land on different XCDs (round-robin deal),
+//              perfectly balanced when pair density varies with height, every L2 sees the same gate window;
+//   kXcdGroup  groups of 32 consecutive logical blocks stay on one XCD, groups rotate over the XCDs;
+//   kXcdSlab   one contiguous eighth of the grid per XCD (best L2 locality, worst balance: top levels are sparse).
+constexpr int kXcdNone = 0, kXcdGroup = 1, kXcdSlab = 2;
+
+template <int MODE>
+__device__ __forceinline__ unsigned place_block(unsigned bid, unsigned nblk) {
+  if constexpr (MODE == kXcdSlab) {
+    return rg::xcd_remap(bid, nblk);
+  } else if constexpr (MODE == kXcdGroup) {
+    constexpr unsigned S = 32;
+    const unsigned super = S * rg::kNumXcd;
+    const unsigned full = nblk / super * super;           // only whole super-groups are permuted (bijective)
+    if (bid >= full) return bid;
+    const unsigned base = bid / super * super, r = bid % super;
+    return base + (r % rg::kNumXcd) * S + r / rg::kNumXcd;
+  } else {
+    return bid;
+  }
+}
+
+using f32x2 = float __attribute__((ext_vector_type(2)));
+
+// v3: lane-contiguous pair mapping.  In step `it` lane l handles pair t + 64*it + l, so one gather
+// wave-instruction covers 64 CONSECUTIVE pairs (about one voxel row: a dozen short runs of consecutive range
+// gates) instead of every 4th pair of 256 -- roughly 3x fewer cache lines per gather, which is what the
+// texture-address unit is billed for.  The CSR itself is streamed with dword loads (256 contiguous bytes per
+// wave-instruction, consecutive instructions consecutive), so no alignment or padding contract is needed.
+template <typename IndT, int NF, int STRIDE, int TILE, int XCD>
+__global__ __launch_bounds__(rg::kBlock) void csr_apply_kernel_v3(
+    const IndT* __restrict__ indptr, const int32_t* __restrict__ gidx, const float* __restrict__ wts,
+    long n_vox, long n_pairs, const float* __restrict__ packed, unsigned last_gate, float fill,
+    float* __restrict__ out) {
+  static_assert(TILE % 64 == 0, "a wave handles 64 pairs per step");
+  constexpr int IT = TILE / 64;
+  __shared__ f32x2 tile_all[rg::kBlock / rg::kWave][TILE * NF];
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  f32x2* tile = tile_all[wv];
+
+  const unsigned blk = place_block<XCD>(blockIdx.x, gridDim.x);
+  const long r0 = ((long)blk * (rg::kBlock / rg::kWave) + wv) * 64;
+  if (r0 >= n_vox) return;  // wave-uniform
+  const long row = r0 + lane;
+  const long seg_b = (long)indptr[r0];
+  const long seg_e = (long)indptr[r0 + 64 < n_vox ? r0 + 64 : n_vox];
+  const int span = (int)(seg_e - seg_b);             // a 64-row chunk never holds 2^31 pairs
+  const int rs_o = (int)((long)indptr[row < n_vox ? row : n_vox] - seg_b);
+  const int re_o = (int)((long)indptr[row + 1 < n_vox ? row + 1 : n_vox] - seg_b);
+  const int q = lane & 3;
+  int qs[4], qe[4], ps[4], pe[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    qs[p] = __shfl(rs_o, 16 * p + (lane >> 2), 64);
+    qe[p] = __shfl(re_o, 16 * p + (lane >> 2), 64);
+    ps[p] = __builtin_amdgcn_readlane(rs_o, 16 * p);
+    pe[p] = __builtin_amdgcn_readlane(re_o, 16 * p + 15);
+  }
+  double acc_p[4][NF], acc_w[4][NF];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int f = 0; f < NF; ++f) { acc_p[p][f] = 0.0; acc_w[p][f] = 0.0; }
+
+  if (span > 0) {
+    const long last = n_pairs - 1;
+    int ci[IT];
+    float cw[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      long j = seg_b + it * 64 + lane;
+      j = j < last ? j : last;                        // clamped slots are computed but never read back
+      ci[it] = gidx[j];
+      cw[it] = wts[j];
+    }
+    for (int t = 0; t < span; t += TILE) {
+      // ---- stream phase -----------------------------------------------------------------------------
+      float val[IT][STRIDE];
+      float w_cur[IT];
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        w_cur[it] = cw[it];
+        load_packed<STRIDE>(packed, min((unsigned)ci[it], last_gate), val[it]);   // clamp: never fault
+      }
+      if (t + TILE < span) {  // prefetch the next tile's CSR; in flight during the row phase
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+          long j = seg_b + t + TILE + it * 64 + lane;
+          j = j < last ? j : last;
+          ci[it] = gidx[j];
+          cw[it] = wts[j];
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          const bool ok = rg::f32_bits(val[it][f]) != RG_EXCLUDED_BITS;
+          f32x2 e;
+          e.x = ok ? w_cur[it] * val[it][f] : 0.0f;
+          e.y = ok ? w_cur[it] : 0.0f;
+          tile[(it * 64 + lane) * NF + f] = e;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+      // ---- row phase: 4 lanes per row, 16 rows per pass ------------------------------------------------
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        if (ps[p] < t + TILE && pe[p] > t) {  // wave-uniform
+          const int a = (qs[p] > t ? qs[p] : t) - t;
+          const int b = (qe[p] < t + TILE ? qe[p] : t + TILE) - t;
+          f32x2 part0[NF], part1[NF];
+#pragma unroll
+          for (int f = 0; f < NF; ++f) { part0[f] = (f32x2)(0.0f); part1[f] = (f32x2)(0.0f); }
+          int j = a + q;
+          for (; j + 4 < b; j += 8) {         // two elements per trip (one ds_read2_b64), two partial sums
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+              part0[f] += tile[j * NF + f];
+              part1[f] += tile[(j + 4) * NF + f];
+            }
+          }
+          if (j < b) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) part0[f] += tile[j * NF + f];
+          }
+#pragma unroll
+          for (int f = 0; f < NF; ++f) {
+            const f32x2 s = part0[f] + part1[f];
+            acc_p[p][f] += (double)s.x;
+            acc_w[p][f] += (double)s.y;
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    float res = fill;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      double sp = acc_p[p][f], sw = acc_w[p][f];
+      sp += __shfl_xor(sp, 1, 64); sw += __shfl_xor(sw, 1, 64);
+      sp += __shfl_xor(sp, 2, 64); sw += __shfl_xor(sw, 2, 64);
+      const float r = sw > 0.0 ? (float)(sp / sw) : fill;
+      const float moved = __shfl(r, 4 * (lane & 15), 64);    // row 16p + k lives in lane 4k
+      if ((lane >> 4) == p) res = moved;
+    }
+    if (row < n_vox) out[(size_t)f * n_vox + row] = res;
+  }
+}
+
+template <typename IndT, int NF, int STRIDE, int TILE, int XCD>
+int launch_v3(const void* indptr, const int32_t* gidx, const float* wts, long n_vox, long n_pairs, const float* packed,
+              long n_gates, float fill, float* out, hipStream_t s) {
+  const long chunks = (n_vox + 63) / 64;
+  const long blocks = (chunks + 3) / 4;
+  hipLaunchKernelGGL((csr_apply_kernel_v3<IndT, NF, STRIDE, TILE, XCD>), dim3((unsigned)blocks), dim3(rg::kBlock), 0, s,
+                     static_cast<const IndT*>(indptr), gidx, wts, n_vox, n_pairs, packed, (unsigned)(n_gates - 1),
+                     fill, out);
+  return rg::check_launch("rg_csr_apply_f32");
+}
+
 template <typename IndT, int NF, int STRIDE, int TILE, bool NT>
 int launch(const void* indptr, const int32_t* gidx, const float* wts, long n_vox, long n_pairs, const float* packed,
            long n_gates, float fill, float* out, hipStream_t s) {
@@ -212,24 +384,28 @@ int dispatch(int nf, int variant, const void* indptr, const int32_t* gidx, const
              const float* packed, long n_gates, float fill, float* out, hipStream_t s) {
 #define RG_K1(NF_, ST_, TILE_, NT_) \
   launch<IndT, NF_, ST_, TILE_, NT_>(indptr, gidx, wts, n_vox, n_pairs, packed, n_gates, fill, out, s)
+#define RG_K3(NF_, ST_, TILE_, XCD_) \
+  launch_v3<IndT, NF_, ST_, TILE_, XCD_>(indptr, gidx, wts, n_vox, n_pairs, packed, n_gates, fill, out, s)
   if (nf == 1) {  // tuning variants exist for the single-field kernel only
     switch (variant) {
-      case 1: return RG_K1(1, 1, 512, false);
-      case 2: return RG_K1(1, 1, 1024, true);
-      case 3: return RG_K1(1, 1, 1024, false);
-      case 4: return RG_K1(1, 1, 256, true);
-      default: return RG_K1(1, 1, 512, true);
+      case 1: return RG_K3(1, 1, 512, kXcdNone);
+      case 2: return RG_K3(1, 1, 512, kXcdSlab);
+      case 3: return RG_K1(1, 1, 512, true);        // v2: quad mapping, slab placement
+      case 4: return RG_K3(1, 1, 256, kXcdNone);
+      case 5: return RG_K3(1, 1, 1024, kXcdNone);
+      default: return RG_K3(1, 1, 512, kXcdGroup);
     }
   }
   switch (nf) {
-    case 2: return RG_K1(2, 2, 512, true);
-    case 3: return RG_K1(3, 4, 256, true);
-    case 4: return RG_K1(4, 4, 256, true);
-    case 5: return RG_K1(5, 8, 256, true);
-    case 6: return RG_K1(6, 8, 256, true);
-    case 7: return RG_K1(7, 8, 256, true);
-    default: return RG_K1(8, 8, 256, true);
+    case 2: return RG_K3(2, 2, 512, kXcdGroup);
+    case 3: return RG_K3(3, 4, 256, kXcdGroup);
+    case 4: return RG_K3(4, 4, 256, kXcdGroup);
+    case 5: return RG_K3(5, 8, 256, kXcdGroup);
+    case 6: return RG_K3(6, 8, 256, kXcdGroup);
+    case 7: return RG_K3(7, 8, 256, kXcdGroup);
+    default: return RG_K3(8, 8, 256, kXcdGroup);
   }
+#undef RG_K3
 #undef RG_K1
 }
 
