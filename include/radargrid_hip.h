@@ -98,9 +98,7 @@ int rg_pack_fields_f32(int32_t n_fields, const float* const* fields_host, const 
  *                      for field f, if that weight sum is > 0; otherwise fill_value.
  * Products are float32 (as in the reference), sums are accumulated in float64 and rounded once.
  * gate indices are clamped to [0, n_gates) before the gather (a corrupt index cannot fault the GPU).
- * indptr must be non-decreasing with indptr[0] = 0 and indptr[n_vox] = n_pairs.  gate_idx and weights are
- * read in 16-byte granules: both allocations must be readable up to the next multiple of 4 elements
- * (any hipMalloc / torch allocation is).
+ * indptr must be non-decreasing with indptr[0] = 0 and indptr[n_vox] = n_pairs.
  * ------------------------------------------------------------------------------------------------- */
 int rg_csr_apply_f32(const void* indptr, int32_t indptr_is_i64, const int32_t* gate_idx, const float* weights,
                      int64_t n_vox, int64_t n_pairs,
