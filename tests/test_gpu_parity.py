@@ -355,3 +355,30 @@ def test_fused_roi_grid_matches_reference(rg, name):
         for i, fname in enumerate(names):
             data, mask = oracle.merge_masks(vol.fields[fname])
             _assert_grid_close(out[i], ref[f"grid_{fname}_qc"], _atol(data, mask))
+
+
+# ------------------------------------------------------------------------------------------------
+# batch driver: fused field-volumes per CSR pass
+# ------------------------------------------------------------------------------------------------
+def test_volume_batch_fuses_passes(rg):
+    """5 volumes x 3 fields through VolumeBatch (2 volumes per fused pass) == per-volume apply_geometry_multi;
+    products reducer keeps only 2-D planes; sharding by (rank, world) picks b mod world."""
+    from radar_processor_amd import batch, synthetic
+    name = "g3_c2_r060_barnes2"
+    meta, ref = load_golden(name)
+    geom = _ref_geometry(rg, name, meta, ref)
+    names = ["DBZH", "ZDR", "RHOHV"]
+    vols = [synthetic.make_volume(12, 360, 1000, seed=s, fields=names) for s in (0, 21, 22, 23, 24)]
+    payload = [{n: (np.ma.getdata(v.fields[n]), np.ma.getmaskarray(v.fields[n])) for n in names} for v in vols]
+    vb = batch.VolumeBatch(geom, names)
+    assert vb.volumes_per_pass == 2
+    grids = vb.grid_shard(payload)
+    assert sorted(grids) == [0, 1, 2, 3, 4]
+    for b, v in enumerate(vols):
+        want = rg.apply_geometry_multi(geom, {n: v.fields[n] for n in names})
+        for i, n in enumerate(names):
+            np.testing.assert_array_equal(grids[b][i].cpu().numpy(), want[n])     # same kernel, same order: bitwise
+    np.testing.assert_array_equal(grids[0][0].cpu().numpy(), rg.apply_geometry(geom, vols[0].fields["DBZH"]))
+    planes = vb.grid_shard(payload, products=lambda g: rg.column_max(g[0]).cpu().numpy(), rank=1, world_size=2)
+    assert sorted(planes) == [1, 3]
+    np.testing.assert_array_equal(planes[3], oracle.column_max(grids[3][0].cpu().numpy(), 0, 19))
