@@ -378,7 +378,9 @@ def test_volume_batch_fuses_passes(rg):
         want = rg.apply_geometry_multi(geom, {n: v.fields[n] for n in names})
         for i, n in enumerate(names):
             np.testing.assert_array_equal(grids[b][i].cpu().numpy(), want[n])     # same kernel, same order: bitwise
-    np.testing.assert_array_equal(grids[0][0].cpu().numpy(), rg.apply_geometry(geom, vols[0].fields["DBZH"]))
+    # a different fused-field count uses a different tile size, i.e. another float32 partial-sum grouping
+    np.testing.assert_allclose(grids[0][0].cpu().numpy(), rg.apply_geometry(geom, vols[0].fields["DBZH"]),
+                               rtol=1e-6, atol=1e-5, equal_nan=True)
     planes = vb.grid_shard(payload, products=lambda g: rg.column_max(g[0]).cpu().numpy(), rank=1, world_size=2)
     assert sorted(planes) == [1, 3]
     np.testing.assert_array_equal(planes[3], oracle.column_max(grids[3][0].cpu().numpy(), 0, 19))
