@@ -48,7 +48,11 @@ def parse_args():
     ap.add_argument("--mode", choices=("csr", "fused"), default="csr",
                     help="csr = precomputed geometry + rg_csr_apply_f32 (K1); fused = rg_roi_grid_f32 (K2, no CSR)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-pairs", type=float, default=6e8, help="upper bound on CSR pairs in the CPU sample")
+    ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"),
+                    help="process-group backend for N>1 (nccl = RCCL; gloo only for rehearsing ranks on one GPU)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rehearsal: every rank uses cuda:0 (needs --dist-backend gloo; RCCL refuses a shared GPU)")
+    ap.add_argument("--cpu-sample-pairs", type=float, default=1.5e9, help="upper bound on CSR pairs in the CPU sample")
     return ap.parse_args()
 
 
@@ -124,11 +128,15 @@ def main():
     if world != args.gpus and world > 1:
         log(f"WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
     n_gpus = world
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = 0 if args.share_device else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)      # RCCL over xGMI
+        else:
+            dist.init_process_group(backend="gloo")
     rg.load_library()
 
     cfg = synthetic.CONFIGS[args.config]
@@ -216,7 +224,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
