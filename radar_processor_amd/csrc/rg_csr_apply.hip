@@ -15,12 +15,14 @@
 //                  gates, i.e. few cache lines per instruction;
 //   stream(t+2)    coalesced dword loads of gate_idx and weights (256 contiguous bytes per wave-instruction,
 //                  consecutive instructions consecutive) -- in flight for a whole iteration;
-//   row phase(t)   LDS is the transposition buffer from pair order to row order.  4 lanes share a row: in
-//                  pass p (p = 0..3) lane l works for row 16p + l/4 and sums every 4th element of that row's
-//                  slice of the tile (float32 partials of <= TILE/4 terms, folded into per-row accumulators
-//                  once per tile); passes whose 16 rows do not touch the tile are skipped wave-uniformly;
-//   epilogue       quad-reduce the 4 sub-lane accumulators in float64, move row r0+l's result to lane l, one
-//                  coalesced 256-byte store per field.
+//   row phase(t)   LDS is the transposition buffer from pair order to row order.  LPR = max(4, stride) lanes
+//                  share a row: lane l of pass p works for row (64/LPR)*p + l/LPR, owns field slot
+//                  f = (l % LPR) % stride of it and sums every (LPR/stride)-th element of that row's slice of
+//                  the tile (float32 partials of one tile, folded into per-pass accumulators once per tile).
+//                  With one field that is 4 sub-lanes per row; with 3-4 fields one lane per (row, field); with
+//                  5-8 fields 8 lanes per row -- the accumulator registers do not grow with the field count.
+//                  Passes whose rows do not touch the tile are skipped wave-uniformly;
+//   epilogue       combine the sub-lanes of a row in float64, divide, store out[f][row].
 //
 // Empty rows cost nothing, long rows only lengthen their own quad's loop; no workgroup barrier, no atomics, no
 // inter-wave communication, so results are bit-reproducible run to run.
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(rg::kBlock) void csr_apply_kernel(
   constexpr int IT = TILE / 64;
   constexpr bool NT = (FLAGS & kNonTemporal) != 0;
   using acc_t = typename std::conditional<(FLAGS & kAcc32) != 0, float, double>::type;
-  __shared__ f32x2 tile_all[rg::kBlock / rg::kWave][TILE * NF];
+  __shared__ f32x2 tile_all[rg::kBlock / rg::kWave][TILE * STRIDE];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: chunk bounds live in SGPRs
   f32x2* tile = tile_all[wv];
@@ -109,21 +111,24 @@ __global__ __launch_bounds__(rg::kBlock) void csr_apply_kernel(
   // row bounds as offsets into the chunk's pair range; lane l <-> row r0 + l
   const int rs_o = (int)((long)indptr[row < n_vox ? row : n_vox] - seg_b);
   const int re_o = (int)((long)indptr[row + 1 < n_vox ? row + 1 : n_vox] - seg_b);
-  // quad layout of the row phase: in pass p lane l serves row 16p + (l >> 2), sub-lane q = l & 3
-  const int q = lane & 3;
-  int qs[4], qe[4], ps[4], pe[4];
+  // row-phase layout: LPR lanes per row = STRIDE field slots x SUB sub-lanes; RPP rows per pass; LPR passes
+  constexpr int LPR = STRIDE > 4 ? STRIDE : 4;
+  constexpr int SUB = LPR / STRIDE;
+  constexpr int RPP = 64 / LPR;
+  constexpr int NPASS = LPR;
+  const int rin = lane % LPR;      // position inside the row's lane group
+  const int fslot = rin % STRIDE;  // field slot this lane sums
+  const int sub = rin / STRIDE;    // which of the SUB interleaved element streams
+  const int rlane = lane / LPR;    // row of the pass this lane serves
+  int ps[NPASS], pe[NPASS];        // pair span of each pass's RPP rows (wave-uniform)
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    qs[p] = __shfl(rs_o, 16 * p + (lane >> 2), 64);
-    qe[p] = __shfl(re_o, 16 * p + (lane >> 2), 64);
-    ps[p] = __builtin_amdgcn_readlane(rs_o, 16 * p);  // pair span of the pass's 16 rows (wave-uniform)
-    pe[p] = __builtin_amdgcn_readlane(re_o, 16 * p + 15);
+  for (int p = 0; p < NPASS; ++p) {
+    ps[p] = __builtin_amdgcn_readlane(rs_o, RPP * p);
+    pe[p] = __builtin_amdgcn_readlane(re_o, RPP * p + RPP - 1);
   }
-  acc_t acc_p[4][NF], acc_w[4][NF];
+  acc_t acc_p[NPASS], acc_w[NPASS];
 #pragma unroll
-  for (int p = 0; p < 4; ++p)
-#pragma unroll
-    for (int f = 0; f < NF; ++f) { acc_p[p][f] = 0; acc_w[p][f] = 0; }
+  for (int p = 0; p < NPASS; ++p) { acc_p[p] = 0; acc_w[p] = 0; }
 
   if (span > 0) {
     // Wave-uniform bases + 32-bit lane offsets: one VGPR per load address.  Slots past the end of the arrays
@@ -172,12 +177,12 @@ __global__ __launch_bounds__(rg::kBlock) void csr_apply_kernel(
 #pragma unroll
       for (int it = 0; it < IT; ++it) {
 #pragma unroll
-        for (int f = 0; f < NF; ++f) {
-          const bool ok = rg::f32_bits(val_n[it][f]) != RG_EXCLUDED_BITS;
+        for (int f = 0; f < STRIDE; ++f) {   // padding slots hold the sentinel -> (0, 0)
+          const bool ok = f < NF && rg::f32_bits(val_n[it][f]) != RG_EXCLUDED_BITS;
           f32x2 e;
           e.x = ok ? w_n[it] * val_n[it][f] : 0.0f;
           e.y = ok ? w_n[it] : 0.0f;
-          tile[(it * 64 + lane) * NF + f] = e;
+          tile[(it * 64 + lane) * STRIDE + f] = e;
         }
       }
       if constexpr ((FLAGS & kFlatOrder) == 0) {
@@ -192,33 +197,24 @@ __global__ __launch_bounds__(rg::kBlock) void csr_apply_kernel(
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-      // ---- row phase: 4 lanes per row, 16 rows per pass --------------------------------------------
+      // ---- row phase: LPR lanes per row, RPP rows per pass ---------------------------------------------
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
+      for (int p = 0; p < NPASS; ++p) {
         if (((FLAGS & kNoRows) != 0) ? (p == 0 && t == 0) : (ps[p] < t + TILE && pe[p] > t)) {  // wave-uniform
-          const int a = (qs[p] > t ? qs[p] : t) - t;
-          const int b = (qe[p] < t + TILE ? qe[p] : t + TILE) - t;
-          f32x2 part0[NF], part1[NF];
-#pragma unroll
-          for (int f = 0; f < NF; ++f) { part0[f] = (f32x2)(0.0f); part1[f] = (f32x2)(0.0f); }
-          int j = a + q;
-          for (; j + 4 < b; j += 8) {  // two elements per trip, two independent partial sums
-#pragma unroll
-            for (int f = 0; f < NF; ++f) {
-              part0[f] += tile[j * NF + f];
-              part1[f] += tile[(j + 4) * NF + f];
-            }
+          const int qs = __shfl(rs_o, RPP * p + rlane, 64);
+          const int qe = __shfl(re_o, RPP * p + rlane, 64);
+          const int a = (qs > t ? qs : t) - t;
+          const int b = (qe < t + TILE ? qe : t + TILE) - t;
+          f32x2 part0 = (f32x2)(0.0f), part1 = (f32x2)(0.0f);
+          int j = a + sub;
+          for (; j + SUB < b; j += 2 * SUB) {  // two elements per trip, two independent partial sums
+            part0 += tile[j * STRIDE + fslot];
+            part1 += tile[(j + SUB) * STRIDE + fslot];
           }
-          if (j < b) {
-#pragma unroll
-            for (int f = 0; f < NF; ++f) part0[f] += tile[j * NF + f];
-          }
-#pragma unroll
-          for (int f = 0; f < NF; ++f) {
-            const f32x2 s = part0[f] + part1[f];
-            acc_p[p][f] += (acc_t)s.x;
-            acc_w[p][f] += (acc_t)s.y;
-          }
+          if (j < b) part0 += tile[j * STRIDE + fslot];
+          const f32x2 sum = part0 + part1;
+          acc_p[p] += (acc_t)sum.x;
+          acc_w[p] += (acc_t)sum.y;
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -227,21 +223,173 @@ __global__ __launch_bounds__(rg::kBlock) void csr_apply_kernel(
     }
   }
 
-  // ---- epilogue: quad reduce in float64, transpose back to lane == row, coalesced store ----------------
+  // ---- epilogue: combine the SUB sub-lanes of every (row, field) in float64, divide, store ----------------
+  float res = fill;
 #pragma unroll
-  for (int f = 0; f < NF; ++f) {
-    float res = fill;
+  for (int p = 0; p < NPASS; ++p) {
+    double sp = (double)acc_p[p], sw = (double)acc_w[p];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      double sp = (double)acc_p[p][f], sw = (double)acc_w[p][f];
-      sp += __shfl_xor(sp, 1, 64); sw += __shfl_xor(sw, 1, 64);
-      sp += __shfl_xor(sp, 2, 64); sw += __shfl_xor(sw, 2, 64);
-      const float r = sw > 0.0 ? (float)(sp / sw) : fill;
-      const float moved = __shfl(r, 4 * (lane & 15), 64);  // row 16p + k lives in lane 4k
-      if ((lane >> 4) == p) res = moved;
+    for (int m = STRIDE; m < LPR; m <<= 1) {  // sub-lanes of one field slot are STRIDE lanes apart
+      sp += __shfl_xor(sp, m, 64);
+      sw += __shfl_xor(sw, m, 64);
     }
-    if (row < n_vox) out[(size_t)f * n_vox + row] = res;
+    const float r = sw > 0.0 ? (float)(sp / sw) : fill;
+    if constexpr (STRIDE == 1) {
+      // one field: row RPP*p + k is held by lane LPR*k; move it to lane == row for one coalesced store
+      const float moved = __shfl(r, LPR * (lane & (RPP - 1)), 64);
+      if ((lane / RPP) == p) res = moved;
+    } else {
+      const long orow = r0 + RPP * p + rlane;
+      if (sub == 0 && fslot < NF && orow < n_vox) out[(size_t)fslot * n_vox + orow] = r;
+    }
   }
+  if constexpr (STRIDE == 1) {
+    if (row < n_vox) out[row] = res;
+  }
+}
+
+// Variant of the kernel above with a DYNAMIC row phase, used for fused multi-field passes: per tile the rows that
+// actually touch it (a contiguous range, found with one ballot) share the 64 lanes -- L = the largest power of
+// two <= 64 / rows (at least `stride`) lanes per row, split into stride field slots x L/stride interleaved
+// element streams -- and the per-row sums live in a small LDS array instead of per-pass registers.  Lane
+// utilisation no longer depends on how many rows a tile happens to hold, and neither registers nor code grow
+// with the field count.  Stream / gather / product phases are identical to csr_apply_kernel.
+template <typename IndT, int NF, int STRIDE, int TILE, int XCD, int FLAGS>
+__global__ __launch_bounds__(rg::kBlock) void csr_apply_dyn_kernel(
+    const IndT* __restrict__ indptr, const int32_t* __restrict__ gidx, const float* __restrict__ wts,
+    long n_vox, long n_pairs, const float* __restrict__ packed, unsigned last_gate, float fill,
+    float* __restrict__ out) {
+  static_assert(TILE % 64 == 0, "a wave handles 64 pairs per step");
+  constexpr int IT = TILE / 64;
+  constexpr bool NT = (FLAGS & kNonTemporal) != 0;
+  constexpr int kLgStride = STRIDE == 1 ? 0 : STRIDE == 2 ? 1 : STRIDE == 4 ? 2 : 3;
+  __shared__ f32x2 tile_all[rg::kBlock / rg::kWave][TILE * STRIDE];
+  __shared__ f32x2 rowacc_all[rg::kBlock / rg::kWave][64 * STRIDE];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  f32x2* tile = tile_all[wv];
+  f32x2* rowacc = rowacc_all[wv];
+
+  const unsigned blk = place_block<XCD>(blockIdx.x, gridDim.x);
+  const long r0 = ((long)blk * (rg::kBlock / rg::kWave) + wv) * 64;
+  if (r0 >= n_vox) return;  // wave-uniform
+  const long row = r0 + lane;
+  const long seg_b = (long)indptr[r0];
+  const long seg_e = (long)indptr[r0 + 64 < n_vox ? r0 + 64 : n_vox];
+  const int span = (int)(seg_e - seg_b);
+  const int rs_o = (int)((long)indptr[row < n_vox ? row : n_vox] - seg_b);
+  const int re_o = (int)((long)indptr[row + 1 < n_vox ? row + 1 : n_vox] - seg_b);
+#pragma unroll
+  for (int f = 0; f < STRIDE; ++f) rowacc[lane * STRIDE + f] = (f32x2)(0.0f);
+
+  if (span > 0) {
+    const int32_t* __restrict__ gi = gidx + seg_b;
+    const float* __restrict__ wi = wts + seg_b;
+    const long tail = n_pairs - 1 - seg_b;
+    const int kmax = tail < 0x3FFFFFFF ? (int)tail : 0x3FFFFFFF;
+    int ci[IT];
+    float cw[IT];
+    float w_n[IT];
+    float val_n[IT][STRIDE];
+
+    auto stream = [&](int t) {
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const int k = min(t + it * 64 + lane, kmax);
+        ci[it] = stream_load<NT>(gi + k);
+        cw[it] = stream_load<NT>(wi + k);
+      }
+    };
+    auto gather = [&]() {
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        w_n[it] = cw[it];
+        load_packed<STRIDE>(packed, min((unsigned)ci[it], last_gate), val_n[it]);  // clamp: never fault
+      }
+    };
+
+    stream(0);
+    gather();
+    if (TILE < span) stream(TILE);
+    for (int t = 0; t < span; t += TILE) {
+      // ---- products of tile t -> LDS ---------------------------------------------------------------
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+#pragma unroll
+        for (int f = 0; f < STRIDE; ++f) {  // padding slots hold the sentinel -> (0, 0)
+          const bool ok = f < NF && rg::f32_bits(val_n[it][f]) != RG_EXCLUDED_BITS;
+          f32x2 e;
+          e.x = ok ? w_n[it] * val_n[it][f] : 0.0f;
+          e.y = ok ? w_n[it] : 0.0f;
+          tile[(it * 64 + lane) * STRIDE + f] = e;
+        }
+      }
+      if (t + TILE < span) {  // gather for tile t+1, CSR stream for tile t+2: in flight during the row phase
+        gather();
+        if (t + 2 * TILE < span) stream(t + 2 * TILE);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+      // ---- dynamic row phase ---------------------------------------------------------------------------
+      const unsigned long long act = __ballot(re_o > rs_o && re_o > t && rs_o < t + TILE);
+      if (act != 0) {  // wave-uniform
+        const int ra = __builtin_ctzll(act), rb = 63 - __builtin_clzll(act);
+        const int nact = rb - ra + 1;
+        int lg = 31 - __builtin_clz(64 / nact);          // lanes per row = 2^lg <= 64 / rows
+        lg = lg < kLgStride ? kLgStride : lg;            // ... but at least one lane per field slot
+        const int rpr = 64 >> lg;                        // rows per round
+        const int rin = lane & ((1 << lg) - 1);
+        const int fslot = rin & (STRIDE - 1);
+        const int sub = rin >> kLgStride, nsub = 1 << (lg - kLgStride);
+        for (int rbase = ra; rbase <= rb; rbase += rpr) {
+          const int myrow = rbase + (lane >> lg);
+          const bool live = myrow <= rb;
+          const int qs = __shfl(rs_o, myrow & 63, 64);
+          const int qe = __shfl(re_o, myrow & 63, 64);
+          const int a = (qs > t ? qs : t) - t;
+          const int b = live ? (qe < t + TILE ? qe : t + TILE) - t : a;
+          f32x2 part0 = (f32x2)(0.0f), part1 = (f32x2)(0.0f);
+          int j = a + sub;
+          for (; j + nsub < b; j += 2 * nsub) {  // two elements per trip, two independent partial sums
+            part0 += tile[j * STRIDE + fslot];
+            part1 += tile[(j + nsub) * STRIDE + fslot];
+          }
+          if (j < b) part0 += tile[j * STRIDE + fslot];
+          f32x2 sum = part0 + part1;
+          for (int m = STRIDE; m < (1 << lg); m <<= 1) {  // fold the interleaved streams of one field slot
+            sum.x += __shfl_xor(sum.x, m, 64);
+            sum.y += __shfl_xor(sum.y, m, 64);
+          }
+          if (live && sub == 0) rowacc[myrow * STRIDE + fslot] += sum;  // one owner per (row, slot): plain RMW
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+
+  // ---- epilogue: lane == row again; one coalesced 256-byte store per field ------------------------------
+  if (row < n_vox) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const f32x2 s = rowacc[lane * STRIDE + f];
+      out[(size_t)f * n_vox + row] = s.y > 0.0f ? (float)((double)s.x / (double)s.y) : fill;
+    }
+  }
+}
+
+template <typename IndT, int NF, int STRIDE, int TILE, int XCD, int FLAGS>
+int launch_dyn(const void* indptr, const int32_t* gidx, const float* wts, long n_vox, long n_pairs, const float* packed,
+               long n_gates, float fill, float* out, hipStream_t s) {
+  const long chunks = (n_vox + 63) / 64;
+  const long blocks = (chunks + 3) / 4;
+  hipLaunchKernelGGL((csr_apply_dyn_kernel<IndT, NF, STRIDE, TILE, XCD, FLAGS>), dim3((unsigned)blocks), dim3(rg::kBlock),
+                     0, s, static_cast<const IndT*>(indptr), gidx, wts, n_vox, n_pairs, packed, (unsigned)(n_gates - 1),
+                     fill, out);
+  return rg::check_launch("rg_csr_apply_f32");
 }
 
 template <typename IndT, int NF, int STRIDE, int TILE, int XCD, int FLAGS>
@@ -260,6 +408,8 @@ int dispatch(int nf, int variant, const void* indptr, const int32_t* gidx, const
              const float* packed, long n_gates, float fill, float* out, hipStream_t s) {
 #define RG_K1(NF_, ST_, TILE_, XCD_, FLAGS_) \
   launch<IndT, NF_, ST_, TILE_, XCD_, FLAGS_>(indptr, gidx, wts, n_vox, n_pairs, packed, n_gates, fill, out, s)
+#define RG_KD(NF_, ST_, TILE_, XCD_, FLAGS_) \
+  launch_dyn<IndT, NF_, ST_, TILE_, XCD_, FLAGS_>(indptr, gidx, wts, n_vox, n_pairs, packed, n_gates, fill, out, s)
   if (nf == 1) {  // tuning variants (tools/tune_k1.py) exist for the single-field kernel only
     switch (variant) {
       case 1: return RG_K1(1, 1, 512, kXcdNone, kAcc32);
@@ -270,21 +420,25 @@ int dispatch(int nf, int variant, const void* indptr, const int32_t* gidx, const
       case 6: return RG_K1(1, 1, 512, kXcdNone, kNonTemporal);
       case 7: return RG_K1(1, 1, 384, kXcdNone, 0);
       case 8: return RG_K1(1, 1, 512, kXcdSlab, 0);
+      case 9: return RG_KD(1, 1, 384, kXcdNone, 0);
+      case 10: return RG_KD(1, 1, 1024, kXcdNone, 0);
       case 11: return RG_K1(1, 1, 512, kXcdNone, kNoGather);   // timing-only ablations
       case 12: return RG_K1(1, 1, 512, kXcdNone, kNoRows);
       case 13: return RG_K1(1, 1, 512, kXcdNone, kNoGather | kNoRows);
-      default: return RG_K1(1, 1, 512, kXcdNone, 0);
+      case 14: return RG_K1(1, 1, 512, kXcdNone, 0);           // static 4-lanes-per-row row phase
+      default: return RG_KD(1, 1, 512, kXcdNone, 0);
     }
   }
   switch (nf) {
-    case 2: return RG_K1(2, 2, 512, kXcdNone, 0);
-    case 3: return RG_K1(3, 4, 256, kXcdNone, 0);
-    case 4: return RG_K1(4, 4, 256, kXcdNone, 0);
-    case 5: return RG_K1(5, 8, 256, kXcdNone, 0);
-    case 6: return RG_K1(6, 8, 256, kXcdNone, 0);
-    case 7: return RG_K1(7, 8, 256, kXcdNone, 0);
-    default: return RG_K1(8, 8, 256, kXcdNone, 0);
+    case 2: return variant == 1 ? RG_K1(2, 2, 512, kXcdNone, 0) : RG_KD(2, 2, 512, kXcdNone, 0);
+    case 3: return variant == 1 ? RG_K1(3, 4, 256, kXcdNone, kAcc32) : RG_KD(3, 4, 256, kXcdNone, 0);
+    case 4: return variant == 1 ? RG_K1(4, 4, 256, kXcdNone, kAcc32) : RG_KD(4, 4, 256, kXcdNone, 0);
+    case 5: return RG_KD(5, 8, 128, kXcdNone, 0);
+    case 6: return RG_KD(6, 8, 128, kXcdNone, 0);
+    case 7: return RG_KD(7, 8, 128, kXcdNone, 0);
+    default: return variant == 1 ? RG_K1(8, 8, 128, kXcdNone, kAcc32) : RG_KD(8, 8, 128, kXcdNone, 0);
   }
+#undef RG_KD
 #undef RG_K1
 }
 

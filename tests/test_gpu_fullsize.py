@@ -59,8 +59,8 @@ def test_c2_constant_field_and_linearity(c2):
     combo = 2.0 * a - 0.5 * b
     out = rg.grid_fields_device(geom, [const, a, b, combo])
     filled = torch.isfinite(out[0])
-    # weighted mean of a constant is the constant (float32 product rounding only)
-    assert float((out[0][filled] - 7.25).abs().max()) <= 7.25 * 3e-7
+    # weighted mean of a constant is the constant up to the float32 rounding of products and tile partial sums
+    assert float((out[0][filled] - 7.25).abs().max()) <= 7.25 * 2e-6
     lengths = geom.device_csr(dev).indptr.to(torch.int64).diff()
     assert bool((filled.view(-1) == (lengths > 0)).all())      # no mask: filled <=> row non-empty
     lin = 2.0 * out[1] - 0.5 * out[2]
@@ -160,7 +160,7 @@ def test_c4_fused_gridder_invariants():
     filled = torch.isfinite(out[0])
     frac = float(filled.float().mean())
     assert 0.6 < frac < 0.9
-    assert float((out[0][filled] + 3.5).abs().max()) <= 3.5 * 3e-7
+    assert float((out[0][filled] + 3.5).abs().max()) <= 3.5 * 2e-6
     assert bool((torch.isfinite(out[1]) <= filled).all())
     valid = dbz[(msk == 0) & torch.isfinite(dbz)]
     seen = out[1][torch.isfinite(out[1])]

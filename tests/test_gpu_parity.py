@@ -377,7 +377,8 @@ def test_volume_batch_fuses_passes(rg):
     for b, v in enumerate(vols):
         want = rg.apply_geometry_multi(geom, {n: v.fields[n] for n in names})
         for i, n in enumerate(names):
-            np.testing.assert_array_equal(grids[b][i].cpu().numpy(), want[n])     # same kernel, same order: bitwise
+            # 6 fused field-volumes vs 3: another tile size, i.e. another float32 partial-sum grouping
+            np.testing.assert_allclose(grids[b][i].cpu().numpy(), want[n], rtol=2e-6, atol=2e-5, equal_nan=True)
     # a different fused-field count uses a different tile size, i.e. another float32 partial-sum grouping
     np.testing.assert_allclose(grids[0][0].cpu().numpy(), rg.apply_geometry(geom, vols[0].fields["DBZH"]),
                                rtol=1e-6, atol=1e-5, equal_nan=True)
