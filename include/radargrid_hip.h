@@ -131,6 +131,19 @@ int rg_cappi_lerp_f32(const float* grid, int64_t n_xy, int32_t k_lo, float w_lo,
                       rg_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * a12  constant-elevation PPI: radar_grid/products.py:168-314.  Per pixel the beam height of the elevation
+ * (4/3-earth model of products.py:70-87 when earth_curvature != 0, flat earth :164-165 otherwise) selects the
+ * altitude; linear != 0 -> float64 lerp between the bracketing levels (`out` is double[ny*nx], products.py:276-309),
+ * linear == 0 -> nearest level (`out` is float[ny*nx], products.py:262-272).  The host passes the scalars NumPy
+ * evaluates once: cos_clamped = max(cos(elev), 0.01), sin(elev), tan(elev), ke_re = ke * 6371000, ke_re_sq = ke_re**2.
+ * xc / yc are the float32 linspace tables of products.py:232-233.
+ * ------------------------------------------------------------------------------------------------- */
+int rg_elevation_ppi_f32(const float* grid, const float* xc, const float* yc, int32_t nz, int32_t ny, int32_t nx,
+                         double cos_clamped, double sin_elev, double tan_elev, double ke_re, double ke_re_sq,
+                         double z_min, double z_max, double z_step, int32_t earth_curvature, int32_t linear,
+                         void* out, rg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * a6/a7  geometry builder: replaces radar_grid/compute.py:18-103 (_process_single_level) and the merge of
  * :232-272.  Membership and weights are evaluated in float64 from the float32 inputs with FP contraction
  * disabled, i.e. the reference's arithmetic: valid gate (fl32(z - radar_altitude) <= toa), d2 < r2,

@@ -324,3 +324,47 @@ def antenna_to_cartesian(ranges_m, az_deg, el_deg):
     z = (r ** 2 + big_r ** 2 + 2.0 * r * big_r * np.sin(el)) ** 0.5 - big_r
     s = big_r * np.arcsin(r * np.cos(el) / (big_r + z))
     return s * np.sin(az), s * np.cos(az), z
+
+
+# --------------------------------------------------------------------------------------------------
+# constant-elevation PPI and beam height (src/radar_grid/products.py:23-314)
+# --------------------------------------------------------------------------------------------------
+def beam_height(ground_range, elevation_deg, radar_altitude=0.0, ke=EFFECTIVE_RADIUS_FACTOR, re=EARTH_RADIUS):
+    """products.py:70-89 -- 4/3-earth beam height; slant range from ground range via max(cos, 0.01)."""
+    el = np.radians(elevation_deg)
+    kr = ke * re
+    sr = ground_range / np.maximum(np.cos(el), 0.01)
+    return np.sqrt(sr ** 2 + kr ** 2 + 2 * sr * kr * np.sin(el)) - kr + radar_altitude
+
+
+def beam_height_flat(ground_range, elevation_deg, radar_altitude=0.0):
+    """products.py:164-165."""
+    return ground_range * np.tan(np.radians(elevation_deg)) + radar_altitude
+
+
+def elevation_ppi(grid, grid_limits, elevation_deg, interpolation="linear", earth_curvature=True,
+                  ke=EFFECTIVE_RADIUS_FACTOR):
+    """products.py:224-314 -- per-pixel target altitude from the beam height (float32 ground range, float64
+    height), then float64 lerp between bracketing levels (NaN outside the grid) or nearest level (float32)."""
+    nz, ny, nx = grid.shape
+    (z_min, z_max), (y_min, y_max), (x_min, x_max) = grid_limits
+    yy, xx = np.meshgrid(np.linspace(y_min, y_max, ny, dtype="float32"),
+                         np.linspace(x_min, x_max, nx, dtype="float32"), indexing="ij")
+    dist = np.sqrt(xx ** 2 + yy ** 2)
+    tz = beam_height(dist, elevation_deg, 0.0, ke=ke) if earth_curvature else beam_height_flat(dist, elevation_deg, 0.0)
+    z_step = (z_max - z_min) / (nz - 1) if nz > 1 else 1.0
+    iy, ix = np.meshgrid(np.arange(ny), np.arange(nx), indexing="ij")
+    if interpolation == "nearest":
+        k = np.round((tz - z_min) / z_step).astype(int)
+        out = grid[np.clip(k, 0, nz - 1), iy, ix]
+        out[~((k >= 0) & (k < nz))] = np.nan
+        return out
+    if interpolation != "linear":
+        raise ValueError(f"Unknown interpolation method: {interpolation}")
+    zf = (tz - z_min) / z_step
+    lo = np.floor(zf).astype(int)
+    w_hi = zf - lo
+    out = (1.0 - w_hi) * grid[np.clip(lo, 0, nz - 1), iy, ix] + w_hi * grid[np.clip(lo + 1, 0, nz - 1), iy, ix]
+    out[tz < z_min] = np.nan
+    out[tz > z_max] = np.nan
+    return out

@@ -17,7 +17,9 @@ from .gate_filters import GateFilter, create_mask_from_filter, device_gate_mask
 from .geometry_builder import RoiSearch, compute_grid_geometry
 from .grid_geometry import DeviceCSR, GridGeometry, load_geometry, save_geometry
 from .grid_products import (EARTH_RADIUS, EFFECTIVE_RADIUS_FACTOR, column_argmax, column_max, column_mean,
-                            column_min, constant_altitude_ppi)
+                            column_min, compute_beam_height, compute_beam_height_flat, compute_beam_height_simple,
+                            constant_altitude_ppi, constant_elevation_ppi, get_beam_height_difference,
+                            get_elevation_from_z_level)
 from .gridding import apply_geometry, apply_geometry_multi, grid_fields_device
 from .roi_grid import roi_grid_fields_device
 from .radar_adaptors import (get_available_fields, get_field_data, get_gate_coordinates, get_radar_altitude,
@@ -32,7 +34,8 @@ __all__ = [
     "apply_geometry", "apply_geometry_multi",
     "get_gate_coordinates", "get_field_data", "get_available_fields", "get_radar_info", "get_radar_altitude",
     "GateFilter", "create_mask_from_filter",
-    "constant_altitude_ppi", "column_max", "column_min", "column_mean",
+    "constant_altitude_ppi", "constant_elevation_ppi", "column_max", "column_min", "column_mean",
+    "get_elevation_from_z_level", "get_beam_height_difference", "compute_beam_height", "compute_beam_height_flat",
     "EARTH_RADIUS", "EFFECTIVE_RADIUS_FACTOR",
     # build-specific additions
     "column_argmax", "grid_fields_device", "roi_grid_fields_device", "device_gate_mask", "RoiSearch", "DeviceCSR",

@@ -53,6 +53,9 @@ SIGNATURES = {
     "rg_column_reduce_f32": (c_int32, [c_void_p, c_int32, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                        c_void_p]),
     "rg_cappi_lerp_f32": (c_int32, [c_void_p, c_int64, c_int32, c_float, c_float, c_void_p, c_void_p]),
+    "rg_elevation_ppi_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_double, c_double,
+                                       c_double, c_double, c_double, c_double, c_double, c_double, c_int32, c_int32,
+                                       c_void_p, c_void_p]),
     "rg_geom_bin_workspace_bytes": (c_int64, [c_int64, c_int32, c_int32]),
     "rg_geom_bin_gates_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, POINTER(CellGrid),
                                         c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),

@@ -151,6 +151,65 @@ __global__ __launch_bounds__(rg::kBlock) void cappi_lerp_kernel(const float* __r
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// constant-elevation PPI (radar_grid/products.py:168-314): per pixel, the beam height of the requested elevation
+// (4/3-earth model products.py:70-87, or flat earth :164-165) picks the altitude, then the column is sampled by
+// linear interpolation between the bracketing levels (float64, products.py:276-309) or at the nearest level
+// (float32, products.py:262-272).  Every operation is an IEEE basic operation in NumPy's order and dtype
+// (float32 for the horizontal distance, float64 afterwards; scalars such as cos/sin of the elevation are
+// evaluated by the host exactly as NumPy does), so the result is bit-identical to the reference.
+// ---------------------------------------------------------------------------------------------------
+struct PpiArgs {
+  double cos_c;    // np.maximum(np.cos(elev), 0.01)
+  double sin_e;    // np.sin(elev)
+  double tan_e;    // np.tan(elev)                (flat earth)
+  double ke_re;    // ke * EARTH_RADIUS
+  double ke_re2;   // ke_re ** 2
+  double z_min, z_max, z_step;
+  int curved, nz, ny, nx;
+};
+
+__device__ __forceinline__ double ppi_target_z(const PpiArgs& a, float x, float y) {
+  // products.py:240 -- float32: xx**2 + yy**2, sqrt
+  const float hd = sqrtf(x * x + y * y);
+  if (a.curved) {
+    const double sr = (double)hd / a.cos_c;                                    // products.py:80
+    const double t = ((2.0 * sr) * a.ke_re) * a.sin_e;                         // products.py:84, left to right
+    return (sqrt((sr * sr + a.ke_re2) + t) - a.ke_re) + 0.0;                   // products.py:83-87, radar_altitude = 0.0
+  }
+  return (double)hd * a.tan_e + 0.0;                                           // products.py:165
+}
+
+template <bool LINEAR>
+__global__ __launch_bounds__(rg::kBlock) void elevation_ppi_kernel(const float* __restrict__ grid,
+                                                                   const float* __restrict__ xc,
+                                                                   const float* __restrict__ yc, PpiArgs a,
+                                                                   double* __restrict__ out64, float* __restrict__ out32) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n_xy = (long)a.ny * a.nx;
+  if (i >= n_xy) return;
+  const int ix = (int)(i % a.nx), iy = (int)(i / a.nx);
+  const double tz = ppi_target_z(a, xc[ix], yc[iy]);
+  const double zf = (tz - a.z_min) / a.z_step;                                 // products.py:263,279
+  if constexpr (LINEAR) {
+    const double fl = floor(zf);
+    const long lo = (long)fl, hi = lo + 1;                                     // products.py:280-281
+    const double w_hi = zf - (double)lo, w_lo = 1.0 - w_hi;                    // products.py:284-285
+    const long lo_s = lo < 0 ? 0 : (lo > a.nz - 1 ? a.nz - 1 : lo);            // products.py:293-294
+    const long hi_s = hi < 0 ? 0 : (hi > a.nz - 1 ? a.nz - 1 : hi);
+    const double v_lo = (double)grid[lo_s * n_xy + i], v_hi = (double)grid[hi_s * n_xy + i];
+    double r = w_lo * v_lo + w_hi * v_hi;                                      // products.py:303
+    if (tz < a.z_min || tz > a.z_max) r = __builtin_nan("");                  // products.py:306,309
+    out64[i] = r;
+  } else {
+    const double rn = rint(zf);                                                // np.round: half to even
+    const long k = (long)rn;
+    const bool valid = k >= 0 && k < a.nz;                                     // products.py:266
+    const long ks = k < 0 ? 0 : (k > a.nz - 1 ? a.nz - 1 : k);
+    out32[i] = valid ? grid[ks * n_xy + i] : __builtin_nanf("");              // products.py:271-272
+  }
+}
+
 template <int OP>
 int launch_column(const float* grid, long n_xy, int z_lo, int z_hi, float* out, int* out_arg, hipStream_t s) {
   const bool vec = (n_xy % 4 == 0) && rg::aligned16(grid) && rg::aligned16(out) && (!out_arg || rg::aligned16(out_arg));
@@ -209,4 +268,24 @@ extern "C" int rg_cappi_lerp_f32(const float* grid, int64_t n_xy, int32_t k_lo, 
                        lo, hi, (long)n_xy, w_lo, w_hi, out);
   }
   return rg::check_launch("rg_cappi_lerp_f32");
+}
+
+extern "C" int rg_elevation_ppi_f32(const float* grid, const float* xc, const float* yc, int32_t nz, int32_t ny, int32_t nx,
+                                    double cos_clamped, double sin_elev, double tan_elev, double ke_re, double ke_re_sq,
+                                    double z_min, double z_max, double z_step, int32_t earth_curvature, int32_t linear,
+                                    void* out, rg_stream_t stream) {
+  RG_REQUIRE(grid && xc && yc && out, RG_EINVAL, "rg_elevation_ppi_f32: null pointer");
+  RG_REQUIRE(nz >= 1 && ny >= 1 && nx >= 1, RG_EINVAL, "rg_elevation_ppi_f32: bad shape (%d,%d,%d)", nz, ny, nx);
+  RG_REQUIRE(z_step != 0.0, RG_EINVAL, "rg_elevation_ppi_f32: z_step is zero");
+  PpiArgs a;
+  a.cos_c = cos_clamped; a.sin_e = sin_elev; a.tan_e = tan_elev; a.ke_re = ke_re; a.ke_re2 = ke_re_sq;
+  a.z_min = z_min; a.z_max = z_max; a.z_step = z_step; a.curved = earth_curvature != 0; a.nz = nz; a.ny = ny; a.nx = nx;
+  const long n_xy = (long)ny * nx;
+  const dim3 g((unsigned)((n_xy + rg::kBlock - 1) / rg::kBlock)), b(rg::kBlock);
+  hipStream_t s = (hipStream_t)stream;
+  if (linear)
+    hipLaunchKernelGGL(elevation_ppi_kernel<true>, g, b, 0, s, grid, xc, yc, a, static_cast<double*>(out), (float*)nullptr);
+  else
+    hipLaunchKernelGGL(elevation_ppi_kernel<false>, g, b, 0, s, grid, xc, yc, a, (double*)nullptr, static_cast<float*>(out));
+  return rg::check_launch("rg_elevation_ppi_f32");
 }

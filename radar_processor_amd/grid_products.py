@@ -23,6 +23,67 @@ EARTH_RADIUS = 6371000.0            # radar_grid/products.py:19
 EFFECTIVE_RADIUS_FACTOR = 4.0 / 3.0  # radar_grid/products.py:20
 
 
+# --------------------------------------------------------------------------------------------------
+# beam-height helpers (radar_grid/products.py:23-165) -- tiny host-side formulas, NumPy like the reference
+# --------------------------------------------------------------------------------------------------
+def compute_beam_height(horizontal_distance, elevation_angle: float, radar_altitude: float = 0.0,
+                        ke: float = EFFECTIVE_RADIUS_FACTOR, re: float = EARTH_RADIUS):
+    """Beam height above sea level with the 4/3 effective-earth-radius model
+    ``h = sqrt(r^2 + (ke Re)^2 + 2 r ke Re sin(el)) - ke Re + h0`` where the slant range is approximated from the
+    ground range as ``r = s / max(cos(el), 0.01)`` (``radar_grid/products.py:70-89``)."""
+    el = np.radians(elevation_angle)
+    r_eff = ke * re
+    slant = horizontal_distance / np.maximum(np.cos(el), 0.01)
+    return np.sqrt(slant**2 + r_eff**2 + 2 * slant * r_eff * np.sin(el)) - r_eff + radar_altitude
+
+
+def compute_beam_height_simple(horizontal_distance, elevation_angle: float, radar_altitude: float = 0.0,
+                               ke: float = EFFECTIVE_RADIUS_FACTOR, re: float = EARTH_RADIUS):
+    """Second-order approximation ``h = r sin(el) + r^2 / (2 ke Re) + h0`` (``radar_grid/products.py:123-136``)."""
+    el = np.radians(elevation_angle)
+    r_eff = ke * re
+    slant = horizontal_distance / np.maximum(np.cos(el), 0.01)
+    return slant * np.sin(el) + (slant**2) / (2 * r_eff) + radar_altitude
+
+
+def compute_beam_height_flat(horizontal_distance, elevation_angle: float, radar_altitude: float = 0.0):
+    """Flat-earth beam height ``s tan(el) + h0`` (``radar_grid/products.py:164-165``)."""
+    return horizontal_distance * np.tan(np.radians(elevation_angle)) + radar_altitude
+
+
+def _ground_range(geometry: GridGeometry, dtype=None):
+    """Horizontal distance of every (y, x) pixel from the radar at the grid origin."""
+    _, ny, nx = geometry.grid_shape
+    (y_lo, y_hi), (x_lo, x_hi) = geometry.grid_limits[1], geometry.grid_limits[2]
+    yy, xx = np.meshgrid(np.linspace(y_lo, y_hi, ny, dtype=dtype), np.linspace(x_lo, x_hi, nx, dtype=dtype), indexing="ij")
+    return np.sqrt(xx**2 + yy**2)
+
+
+def get_beam_height_difference(geometry: GridGeometry, elevation_angle: float, radar_altitude: float = 0.0,
+                               ke: float = EFFECTIVE_RADIUS_FACTOR):
+    """Curved-minus-flat beam height on the grid's (y, x) plane, float64 ``(ny, nx)``
+    (``radar_grid/products.py:583-626``)."""
+    dist = _ground_range(geometry)
+    return (compute_beam_height(dist, elevation_angle, radar_altitude, ke=ke)
+            - compute_beam_height_flat(dist, elevation_angle, radar_altitude))
+
+
+def get_elevation_from_z_level(z_level: float, geometry: GridGeometry, radar_altitude: float = 0.0,
+                               earth_curvature: bool = True, ke: float = EFFECTIVE_RADIUS_FACTOR):
+    """Elevation angle (degrees) whose beam reaches ``z_level`` at every (y, x) pixel
+    (``radar_grid/products.py:629-697``): flat-earth arctangent, refined by five fixed-point steps on the
+    4/3-earth height when ``earth_curvature``."""
+    dist = np.maximum(_ground_range(geometry), 1.0)          # avoid the singularity at the radar
+    el = np.arctan((z_level - radar_altitude) / dist)
+    if earth_curvature:
+        r_eff = ke * EARTH_RADIUS
+        for _ in range(5):
+            slant = dist / np.maximum(np.cos(el), 0.01)
+            height = np.sqrt(slant**2 + r_eff**2 + 2 * slant * r_eff * np.sin(el)) - r_eff + radar_altitude
+            el = np.clip(el + (z_level - height) / (slant + 1), -np.pi / 2, np.pi / 2)
+    return np.degrees(el)
+
+
 def _is_tensor(x) -> bool:
     return type(x).__module__.startswith("torch")
 
@@ -93,6 +154,39 @@ def constant_altitude_ppi(grid, geometry: GridGeometry, altitude: float, interpo
         _native.check(lib.rg_cappi_lerp_f32(_native.ptr(g), ny * nx, z_low, float(np.float32(weight_low)),
                                             float(np.float32(weight_high)), _native.ptr(out), _native.stream_ptr()),
                       "rg_cappi_lerp_f32")
+    return _finish(out, as_numpy)
+
+
+def constant_elevation_ppi(grid, geometry: GridGeometry, elevation_angle: float, interpolation: str = "linear",
+                           earth_curvature: bool = True, ke: float = EFFECTIVE_RADIUS_FACTOR):
+    """PPI at a constant elevation angle sampled from the 3-D grid (``radar_grid/products.py:168-314``).
+
+    For every (y, x) the beam height of ``elevation_angle`` (4/3-earth model, or flat earth) is the target
+    altitude; ``'linear'`` interpolates between the bracketing levels and returns float64 (NaN outside
+    ``[z_min, z_max]``), ``'nearest'`` samples the nearest level and returns float32.  Runs in
+    ``rg_elevation_ppi_f32``; bit-identical to the reference's NumPy evaluation.
+    """
+    if interpolation not in ("linear", "nearest"):
+        raise ValueError(f"Unknown interpolation method: {interpolation}")
+    nz, ny, nx = (int(v) for v in geometry.grid_shape)
+    z_min, z_max = geometry.grid_limits[0]
+    (y_lo, y_hi), (x_lo, x_hi) = geometry.grid_limits[1], geometry.grid_limits[2]
+    z_step = (z_max - z_min) / (nz - 1) if nz > 1 else 1.0
+    el = np.radians(elevation_angle)
+    r_eff = ke * EARTH_RADIUS
+    torch = _native.torch_mod()
+    lib = _native.load_library()
+    g, as_numpy = _to_device_grid(grid)
+    xc = torch.from_numpy(np.linspace(x_lo, x_hi, nx, dtype="float32")).to(g.device)
+    yc = torch.from_numpy(np.linspace(y_lo, y_hi, ny, dtype="float32")).to(g.device)
+    linear = interpolation == "linear"
+    out = torch.empty((ny, nx), dtype=torch.float64 if linear else torch.float32, device=g.device)
+    with torch.cuda.device(g.device):
+        _native.check(lib.rg_elevation_ppi_f32(
+            _native.ptr(g), _native.ptr(xc), _native.ptr(yc), nz, ny, nx, float(np.maximum(np.cos(el), 0.01)),
+            float(np.sin(el)), float(np.tan(el)), float(r_eff), float(r_eff**2), float(z_min), float(z_max),
+            float(z_step), int(bool(earth_curvature)), int(linear), _native.ptr(out), _native.stream_ptr()),
+            "rg_elevation_ppi_f32")
     return _finish(out, as_numpy)
 
 

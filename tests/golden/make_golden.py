@@ -181,6 +181,37 @@ def gen_g5(ref, synth):
         print("g5", tag)
 
 
+def gen_g7(ref, synth):
+    """Constant-elevation PPI + beam-height helpers on a grid wide enough for the beam to cross all levels."""
+    rng = np.random.default_rng(77)
+    shape = (20, 48, 64)
+    grid = rng.normal(12.0, 15.0, size=shape).astype(np.float32)
+    grid[rng.random(shape) < 0.2] = np.nan
+    limits = ((0.0, 15000.0), (-110e3, 110e3), (-150e3, 150e3))
+    geom = ref.geometry.GridGeometry(grid_shape=shape, grid_limits=limits, indptr=np.zeros(grid.size + 1, dtype=np.int32),
+                                     gate_indices=np.zeros(0, dtype=np.int32), weights=np.zeros(0, dtype=np.float32),
+                                     toa=17000.0, radar_altitude=312.0)
+    out = dict(grid=grid)
+    P = ref.products
+    for elev in (0.0, 0.5, 2.0, 10.0, 45.0):
+        for interp in ("linear", "nearest"):
+            for curved in (True, False):
+                key = f"ppi_e{elev}_{interp}_{'curved' if curved else 'flat'}"
+                out[key] = np.array(P.constant_elevation_ppi(grid, geom, elev, interpolation=interp, earth_curvature=curved))
+    out["ppi_e2.0_linear_ke1"] = np.array(P.constant_elevation_ppi(grid, geom, 2.0, ke=1.0))
+    d = np.array([0.0, 1.0, 10000.0, 20000.0, 50000.0, 237000.5])
+    out["bh_dist"] = d
+    out["bh_curved"] = P.compute_beam_height(d, 2.0, 100.0)
+    out["bh_simple"] = P.compute_beam_height_simple(d, 2.0, 100.0)
+    out["bh_flat"] = P.compute_beam_height_flat(d, 2.0, 100.0)
+    out["bh_difference"] = P.get_beam_height_difference(geom, 1.5, radar_altitude=312.0)
+    out["elev_from_z_curved"] = P.get_elevation_from_z_level(3000.0, geom, radar_altitude=312.0)
+    out["elev_from_z_flat"] = P.get_elevation_from_z_level(3000.0, geom, radar_altitude=312.0, earth_curvature=False)
+    out["meta"] = meta_blob(case="G7", grid_shape=shape, grid_limits=limits, radar_altitude=312.0)
+    np.savez_compressed(os.path.join(HERE, "g7_ppi.npz"), **out)
+    print("g7")
+
+
 def gen_g6(ref, synth):
     """radar_altitude != 0 pins the compute.py:182 subtraction and the toa cut; low toa drops sweeps."""
     vol = synth.make_volume(n_elev=12, n_az=360, n_gates=1000, seed=6, fields=("DBZH",))
@@ -201,7 +232,7 @@ def main():
     args = ap.parse_args()
     ref = load_reference()
     from radar_processor_amd import synthetic as synth
-    gens = dict(g2=gen_g2, g3=gen_g3, g4=gen_g4, g5=gen_g5, g6=gen_g6)
+    gens = dict(g2=gen_g2, g3=gen_g3, g4=gen_g4, g5=gen_g5, g6=gen_g6, g7=gen_g7)
     for name, fn in gens.items():
         if args.only and name not in args.only:
             continue

@@ -385,3 +385,27 @@ def test_volume_batch_fuses_passes(rg):
     planes = vb.grid_shard(payload, products=lambda g: rg.column_max(g[0]).cpu().numpy(), rank=1, world_size=2)
     assert sorted(planes) == [1, 3]
     np.testing.assert_array_equal(planes[3], oracle.column_max(grids[3][0].cpu().numpy(), 0, 19))
+
+
+# ------------------------------------------------------------------------------------------------
+# constant-elevation PPI (rg_elevation_ppi_f32): bit-identical to the reference's float64 / float32 results
+# ------------------------------------------------------------------------------------------------
+def test_elevation_ppi_matches_reference_bitwise(rg):
+    import torch
+    meta, ref = load_golden("g7_ppi")
+    limits = tuple(tuple(v) for v in meta["grid_limits"])
+    grid = ref["grid"]
+    geom = rg.GridGeometry(grid.shape, limits, np.zeros(grid.size + 1, dtype=np.int32), np.zeros(0, dtype=np.int32),
+                           np.zeros(0, dtype=np.float32), toa=17000.0, radar_altitude=meta["radar_altitude"])
+    n = 0
+    for key in sorted(k for k in ref if k.startswith("ppi_e") and not k.endswith("_ke1")):
+        _, e, interp, curv = key.split("_")
+        got = rg.constant_elevation_ppi(grid, geom, float(e[1:]), interpolation=interp, earth_curvature=(curv == "curved"))
+        assert got.dtype == ref[key].dtype, key              # float64 for 'linear' (reference test :262), float32 nearest
+        np.testing.assert_array_equal(got, ref[key], err_msg=key)
+        n += 1
+    assert n == 20
+    np.testing.assert_array_equal(rg.constant_elevation_ppi(grid, geom, 2.0, ke=1.0), ref["ppi_e2.0_linear_ke1"])
+    dev_out = rg.constant_elevation_ppi(torch.from_numpy(grid).cuda(), geom, 2.0)
+    assert dev_out.is_cuda and dev_out.dtype == torch.float64
+    np.testing.assert_array_equal(dev_out.cpu().numpy(), ref["ppi_e2.0_linear_curved"])

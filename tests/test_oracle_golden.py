@@ -211,3 +211,51 @@ def test_antenna_transform_agrees_with_package():
     el = np.array([0.5, 3.0, 11.8, 25.0])[:, None]
     for a, b in zip(oracle.antenna_to_cartesian(r, az, el), synthetic.antenna_to_cartesian(r, az, el)):
         np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------
+# constant-elevation PPI + beam-height helpers
+# ------------------------------------------------------------------------------------------------
+def _ppi_cases(ref):
+    for key in sorted(k for k in ref if k.startswith("ppi_e") and not k.endswith("_ke1")):
+        _, e, interp, curv = key.split("_")
+        yield key, float(e[1:]), interp, curv == "curved"
+
+
+def test_elevation_ppi_oracle_matches_reference():
+    meta, ref = load_golden("g7_ppi")
+    limits = tuple(tuple(v) for v in meta["grid_limits"])
+    for key, elev, interp, curved in _ppi_cases(ref):
+        got = oracle.elevation_ppi(ref["grid"], limits, elev, interp, curved)
+        assert got.dtype == ref[key].dtype == (np.float64 if interp == "linear" else np.float32)
+        np.testing.assert_array_equal(got, ref[key], err_msg=key)
+    np.testing.assert_array_equal(oracle.elevation_ppi(ref["grid"], limits, 2.0, ke=1.0), ref["ppi_e2.0_linear_ke1"])
+    np.testing.assert_array_equal(oracle.beam_height(ref["bh_dist"], 2.0, 100.0), ref["bh_curved"])
+    np.testing.assert_array_equal(oracle.beam_height_flat(ref["bh_dist"], 2.0, 100.0), ref["bh_flat"])
+
+
+def test_beam_height_helpers_match_reference():
+    """Host-side helpers of the product package (plain NumPy formulas, no GPU involved)."""
+    import radar_processor_amd as rg
+    meta, ref = load_golden("g7_ppi")
+    limits = tuple(tuple(v) for v in meta["grid_limits"])
+    geom = rg.GridGeometry(tuple(meta["grid_shape"]), limits, np.zeros(2, dtype=np.int32), np.zeros(0, dtype=np.int32),
+                           np.zeros(0, dtype=np.float32), toa=17000.0, radar_altitude=meta["radar_altitude"])
+    d = ref["bh_dist"]
+    np.testing.assert_array_equal(rg.compute_beam_height(d, 2.0, 100.0), ref["bh_curved"])
+    np.testing.assert_array_equal(rg.compute_beam_height_simple(d, 2.0, 100.0), ref["bh_simple"])
+    np.testing.assert_array_equal(rg.compute_beam_height_flat(d, 2.0, 100.0), ref["bh_flat"])
+    diff = rg.get_beam_height_difference(geom, 1.5, radar_altitude=312.0)
+    assert diff.dtype == np.float64
+    np.testing.assert_array_equal(diff, ref["bh_difference"])
+    np.testing.assert_array_equal(rg.get_elevation_from_z_level(3000.0, geom, radar_altitude=312.0), ref["elev_from_z_curved"])
+    np.testing.assert_array_equal(rg.get_elevation_from_z_level(3000.0, geom, radar_altitude=312.0, earth_curvature=False),
+                                  ref["elev_from_z_flat"])
+    # reference unit tests (tests/test_radar_grid_products.py:30-91): monotone in range, flat-earth linearity
+    h = rg.compute_beam_height(np.array([10000.0, 20000.0, 50000.0]), 2.0, 100.0)
+    assert np.all(h > 100.0) and h[0] < h[1] < h[2]
+    assert rg.compute_beam_height(np.array([10000.0]), 45.0, 0.0)[0] > 7000.0
+    hf = rg.compute_beam_height_flat(np.array([10000.0, 20000.0]), 2.0, 100.0)
+    np.testing.assert_almost_equal(hf[1] - hf[0], 10000.0 * np.tan(np.radians(2.0)), decimal=1)
+    with pytest.raises(ValueError, match="Unknown interpolation method"):
+        rg.constant_elevation_ppi(ref["grid"], geom, 2.0, interpolation="cubic")
