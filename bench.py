@@ -176,7 +176,7 @@ def main():
         gridder = CsrGridder(geom, n_gates, n_ff, device=dev)
         n_pairs = gridder.csr.n_pairs
         algo_bytes = gridder.algorithmic_bytes()
-        kernel_name = "csr_apply_kernel"
+        kernel_name = "csr_apply_dyn_kernel"
     else:
         from radar_processor_amd.roi_grid import roi_grid_fields_device
         search = rg.RoiSearch(vol.gate_x, vol.gate_y, vol.gate_z, shape, limits, device=dev)

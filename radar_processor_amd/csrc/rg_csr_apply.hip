@@ -422,6 +422,10 @@ int dispatch(int nf, int variant, const void* indptr, const int32_t* gidx, const
       case 8: return RG_K1(1, 1, 512, kXcdSlab, 0);
       case 9: return RG_KD(1, 1, 384, kXcdNone, 0);
       case 10: return RG_KD(1, 1, 1024, kXcdNone, 0);
+      case 15: return RG_KD(1, 1, 512, kXcdNone, kNonTemporal);
+      case 16: return RG_KD(1, 1, 512, kXcdGroup, 0);
+      case 17: return RG_KD(1, 1, 640, kXcdNone, 0);
+      case 18: return RG_KD(1, 1, 256, kXcdNone, 0);
       case 11: return RG_K1(1, 1, 512, kXcdNone, kNoGather);   // timing-only ablations
       case 12: return RG_K1(1, 1, 512, kXcdNone, kNoRows);
       case 13: return RG_K1(1, 1, 512, kXcdNone, kNoGather | kNoRows);

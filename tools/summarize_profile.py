@@ -53,7 +53,7 @@ def main():
         line = open(bench).read().strip().splitlines()[-1]
         info = json.loads(line)
         key = info["config"]["key"]
-        kern = info["roofline"]["kernel"].replace("_kernel", "")
+        kern = info["roofline"]["kernel"].replace("_dyn_kernel", "").replace("_kernel", "")
         fetch = [v for (k, c), v in agg.items() if c == "FETCH_SIZE" and kern in k]
         write = [v for (k, c), v in agg.items() if c == "WRITE_SIZE" and kern in k]
         if fetch and write:
