@@ -80,6 +80,10 @@ def load_library(require_device: bool = True):
     global _lib
     with _lock:
         if _lib is None:
+            # PyTorch-ROCm ships its own HIP runtime; it must be the one already loaded when our library is
+            # dlopen-ed, so that both share ONE runtime (streams and device pointers are only meaningful within it).
+            # Loading ours first would pull in the system libamdhip64 and leave torch without a usable device.
+            torch_mod()
             if not os.path.exists(LIB_PATH):
                 raise NativeUnavailable(
                     f"{LIB_PATH} is missing: build it with `python -m radar_processor_amd.build` "

@@ -164,6 +164,19 @@ def grid_fields_device(geometry: GridGeometry, fields: Sequence, masks: Optional
     return out.view(n_fields, nz, ny, nx)
 
 
+def _to_host(t) -> np.ndarray:
+    """Device -> NumPy through a page-locked staging tensor (about twice the rate of a pageable copy; the
+    640 MB grid download dominates the NumPy-in / NumPy-out path).  The array owns its buffer."""
+    torch = _native.torch_mod()
+    try:
+        host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    except RuntimeError:        # no pinned memory available: plain copy
+        return t.cpu().numpy()
+    host.copy_(t, non_blocking=True)
+    torch.cuda.current_stream(t.device).synchronize()
+    return host.numpy()
+
+
 def apply_geometry(geometry: GridGeometry, field_data: np.ndarray,
                    additional_filters: Optional[List[GateFilter]] = None,
                    fill_value: float = np.nan) -> np.ndarray:
@@ -180,7 +193,7 @@ def apply_geometry(geometry: GridGeometry, field_data: np.ndarray,
     f_t = torch.from_numpy(values).to(dev)
     m_t = torch.from_numpy(mask).to(dev) if mask.any() else None
     grid = grid_fields_device(geometry, [f_t], [m_t], fill_value=fill_value)
-    return grid[0].cpu().numpy().reshape(geometry.grid_shape)
+    return _to_host(grid[0]).reshape(geometry.grid_shape)
 
 
 def apply_geometry_multi(geometry: GridGeometry, fields: Dict[str, np.ndarray],
@@ -202,5 +215,5 @@ def apply_geometry_multi(geometry: GridGeometry, fields: Dict[str, np.ndarray],
         values, mask = _host_field(fields[name], _coerce_filters(additional_filters.get(name, None)))
         f_ts.append(torch.from_numpy(values).to(dev))
         m_ts.append(torch.from_numpy(mask).to(dev) if mask.any() else None)
-    grid = grid_fields_device(geometry, f_ts, m_ts, fill_value=fill_value).cpu().numpy()
+    grid = _to_host(grid_fields_device(geometry, f_ts, m_ts, fill_value=fill_value))
     return {name: grid[i].reshape(geometry.grid_shape) for i, name in enumerate(names)}
