@@ -15,16 +15,14 @@
 //                  gates, i.e. few cache lines per instruction;
 //   stream(t+2)    coalesced dword loads of gate_idx and weights (256 contiguous bytes per wave-instruction,
 //                  consecutive instructions consecutive) -- in flight for a whole iteration;
-//   row phase(t)   LDS is the transposition buffer from pair order to row order.  LPR = max(4, stride) lanes
-//                  share a row: lane l of pass p works for row (64/LPR)*p + l/LPR, owns field slot
-//                  f = (l % LPR) % stride of it and sums every (LPR/stride)-th element of that row's slice of
-//                  the tile (float32 partials of one tile, folded into per-pass accumulators once per tile).
-//                  With one field that is 4 sub-lanes per row; with 3-4 fields one lane per (row, field); with
-//                  5-8 fields 8 lanes per row -- the accumulator registers do not grow with the field count.
-//                  Passes whose rows do not touch the tile are skipped wave-uniformly;
-//   epilogue       combine the sub-lanes of a row in float64, divide, store out[f][row].
+//   row phase(t)   LDS is the transposition buffer from pair order to row order.  Two implementations:
+//                  csr_apply_dyn_kernel (DEFAULT): the rows that touch the tile share the 64 lanes dynamically,
+//                  per-row sums live in LDS (see the comment at that kernel);
+//                  csr_apply_kernel (tuning variant): a static layout, LPR = max(4, stride) lanes per row and
+//                  64/LPR rows per pass, per-pass accumulators in registers;
+//   epilogue       combine, divide in float64, coalesced store of out[f][row].
 //
-// Empty rows cost nothing, long rows only lengthen their own quad's loop; no workgroup barrier, no atomics, no
+// Empty rows cost nothing, long rows only lengthen their own lanes' loop; no workgroup barrier, no atomics, no
 // inter-wave communication, so results are bit-reproducible run to run.
 #include <type_traits>
 
