@@ -157,13 +157,14 @@ extern "C" int rg_gate_mask_f32(const float* data, int64_t n_gates, int32_t op, 
 extern "C" int rg_pack_fields_f32(int32_t n_fields, const float* const* fields_host,
                                   const uint8_t* const* masks_host, const uint8_t* shared_mask, int64_t n_gates,
                                   int32_t stride, float* packed, rg_stream_t stream) {
-  RG_REQUIRE(fields_host && packed, RG_EINVAL, "rg_pack_fields_f32: null pointer");
+  RG_REQUIRE(fields_host && (packed || n_gates == 0), RG_EINVAL, "rg_pack_fields_f32: null pointer");
   RG_REQUIRE(n_fields >= 1 && n_fields <= RG_MAX_FIELDS, RG_EUNSUPPORTED, "rg_pack_fields_f32: n_fields=%d not in 1..%d",
              n_fields, RG_MAX_FIELDS);
   RG_REQUIRE((stride == 1 || stride == 2 || stride == 4 || stride == 8) && stride >= n_fields, RG_EINVAL,
              "rg_pack_fields_f32: stride=%d must be 1,2,4,8 and >= n_fields=%d", stride, n_fields);
   RG_REQUIRE(n_gates >= 0, RG_EINVAL, "rg_pack_fields_f32: negative size");
   RG_REQUIRE(rg::aligned16(packed), RG_EALIGN, "rg_pack_fields_f32: packed must be 16-byte aligned");
+  if (n_gates == 0) return RG_OK;  // nothing to pack (zero-size buffers may legitimately be null)
   PackArgs a;
   memset(&a, 0, sizeof(a));
   for (int f = 0; f < n_fields; ++f) {
@@ -172,7 +173,6 @@ extern "C" int rg_pack_fields_f32(int32_t n_fields, const float* const* fields_h
     a.mask[f] = masks_host ? masks_host[f] : nullptr;
   }
   a.shared = shared_mask;
-  if (n_gates == 0) return RG_OK;
   const dim3 grid(blocks_for(n_gates, rg::kBlock)), block(rg::kBlock);
   hipStream_t s = (hipStream_t)stream;
   switch (stride) {

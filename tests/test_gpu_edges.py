@@ -1,0 +1,131 @@
+"""Edge cases of the HIP path against the CPU oracle on small *random point clouds* (the builder and the fused
+gridder take arbitrary gate coordinates, not only polar volumes): degenerate grid shapes, grids that are not a
+multiple of the wavefront, search boxes spanning more than 64 cell rows, constant ROI, ROI larger than the grid,
+no gate in reach, everything masked, top-of-atmosphere cuts, non-finite coordinates."""
+import numpy as np
+import pytest
+
+from oracle import radar_grid_oracle as oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rg():
+    import radar_processor_amd as pkg
+    pkg.load_library()
+    return pkg
+
+
+def _cloud(seed, n, extent=20e3, zmax=9e3):
+    rng = np.random.default_rng(seed)
+    gx = rng.uniform(-extent, extent, n).astype(np.float32)
+    gy = rng.uniform(-extent, extent, n).astype(np.float32)
+    gz = rng.uniform(0, zmax, n).astype(np.float32)
+    val = rng.normal(20, 10, n).astype(np.float32)
+    mask = rng.random(n) < 0.15
+    return gx, gy, gz, val, mask
+
+
+def _check(rg, gx, gy, gz, val, mask, shape, limits, tmp_path, cell_size=None, **kw):
+    import torch
+    weighting = kw.pop("weighting", "barnes2")
+    o_ip, o_idx, o_w = oracle.build_geometry(gx, gy, gz, shape, limits, weighting=weighting, **kw)
+    want = oracle.csr_apply(o_ip, o_idx, o_w, val, mask, shape)
+    # CSR path
+    geom = rg.compute_grid_geometry(gx, gy, gz, shape, limits, str(tmp_path), weighting=weighting, **kw)
+    ip, idx, w = oracle.canonical_rows(geom.indptr, geom.gate_indices, geom.weights)
+    np.testing.assert_array_equal(ip, o_ip)
+    np.testing.assert_array_equal(idx, o_idx)
+    if weighting == "barnes2":
+        assert np.abs(w.view(np.int32).astype(np.int64) - o_w.view(np.int32).astype(np.int64)).max(initial=0) <= 1
+    else:
+        np.testing.assert_array_equal(w, o_w)
+    got = rg.apply_geometry(geom, np.ma.array(val, mask=mask))
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5 * 60, equal_nan=True)
+    # fused path (optionally with a forced cell size)
+    kw2 = {k: v for k, v in kw.items()}
+    search = rg.RoiSearch(gx, gy, gz, shape, limits, cell_size=cell_size, **kw2)
+    f = torch.from_numpy(val).to(search.dev)
+    m = torch.from_numpy(mask.astype(np.uint8)).to(search.dev)
+    fused = rg.roi_grid_fields_device(search, [f], [m], weighting=weighting)[0].cpu().numpy()
+    np.testing.assert_array_equal(np.isnan(fused), np.isnan(want))
+    np.testing.assert_allclose(fused, want, rtol=1e-5, atol=1e-5 * 60, equal_nan=True)
+    return geom
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1), (1, 1, 65), (2, 3, 1), (3, 1, 130), (1, 7, 63), (4, 5, 64), (2, 9, 200)])
+def test_degenerate_and_ragged_grid_shapes(rg, tmp_path, shape):
+    gx, gy, gz, val, mask = _cloud(1, 4000)
+    nz, ny, nx = shape
+    limits = ((500.0, 500.0 if nz == 1 else 6000.0), (-3e3, -3e3 if ny == 1 else 9e3), (-15e3, -15e3 if nx == 1 else 15e3))
+    _check(rg, gx, gy, gz, val, mask, shape, limits, tmp_path, min_radius=900.0, beam_factor=0.05)
+
+
+@pytest.mark.parametrize("weighting", ["barnes2", "cressman", "nearest"])
+def test_search_box_spanning_more_than_64_cell_rows(rg, tmp_path, weighting):
+    """ROI 3 km over 40 m cells = 150 cell rows per voxel: exercises the chunked row-bounds loop of the fused
+    gridder (and long runs in the builder)."""
+    gx, gy, gz, val, mask = _cloud(2, 6000, extent=8e3, zmax=3e3)
+    shape, limits = (2, 6, 70), ((0.0, 2000.0), (-2e3, 2e3), (-5e3, 5e3))
+    _check(rg, gx, gy, gz, val, mask, shape, limits, tmp_path, cell_size=40.0, min_radius=3000.0, beam_factor=0.0,
+           weighting=weighting)
+
+
+def test_constant_roi_and_roi_larger_than_the_grid(rg, tmp_path):
+    gx, gy, gz, val, mask = _cloud(3, 1500, extent=5e3, zmax=2e3)
+    shape, limits = (2, 4, 9), ((0.0, 1000.0), (-1e3, 1e3), (-2e3, 2e3))
+    geom = _check(rg, gx, gy, gz, val, mask, shape, limits, tmp_path, min_radius=50e3, beam_factor=0.0)
+    assert geom.n_pairs() == 1500 * 72                     # every gate is a neighbour of every voxel
+
+
+def test_no_gate_in_reach_all_masked_and_toa(rg, tmp_path):
+    import torch
+    gx, gy, gz, val, mask = _cloud(4, 3000)
+    shape, limits = (3, 8, 70), ((0.0, 8000.0), (-10e3, 10e3), (-12e3, 12e3))
+    # gates far away from the grid: empty geometry, all fill
+    far = rg.compute_grid_geometry(gx + 5e5, gy, gz, shape, limits, str(tmp_path))
+    assert far.n_pairs() == 0 and np.all(rg.apply_geometry(far, np.ma.array(val, mask=mask), fill_value=-1.0) == -1.0)
+    # every gate masked -> all NaN although the geometry is dense
+    geom = _check(rg, gx, gy, gz, val, np.ones_like(mask), shape, limits, tmp_path, min_radius=1500.0)
+    assert geom.n_pairs() > 0
+    # toa removes the upper gates (float32 comparison of z - radar_altitude, compute.py:182,193)
+    _check(rg, gx, gy, gz, val, mask, shape, limits, tmp_path, min_radius=1500.0, toa=4000.0, radar_altitude=250.0)
+    # toa = inf (load_geometry default) keeps everything
+    _check(rg, gx, gy, gz, val, mask, shape, limits, tmp_path, min_radius=1500.0, toa=float("inf"))
+    # non-finite gate coordinates are dropped, not propagated
+    bad = gx.copy()
+    bad[::50] = np.nan
+    good = np.isfinite(bad)
+    a = rg.compute_grid_geometry(bad, gy, gz, shape, limits, str(tmp_path), min_radius=1500.0)
+    o_ip, o_idx, _ = oracle.build_geometry(gx[good], gy[good], gz[good], shape, limits, min_radius=1500.0)
+    remap = np.nonzero(good)[0]
+    ip, idx, _ = oracle.canonical_rows(a.indptr, a.gate_indices, a.weights)
+    np.testing.assert_array_equal(ip, o_ip)
+    np.testing.assert_array_equal(idx, remap[o_idx])
+
+
+def test_zero_gates(rg, tmp_path):
+    z = np.zeros(0, dtype=np.float32)
+    geom = rg.compute_grid_geometry(z, z, z, (2, 3, 4), ((0.0, 1000.0), (-1e3, 1e3), (-1e3, 1e3)), str(tmp_path))
+    assert geom.n_pairs() == 0 and geom.indptr.shape == (25,)
+    out = rg.apply_geometry(geom, np.ma.array(z, mask=np.zeros(0, dtype=bool)))
+    assert out.shape == (2, 3, 4) and np.all(np.isnan(out))
+
+
+def test_unmasked_nan_reaches_only_its_neighbours_in_the_fused_gridder(rg):
+    """Voxel blocking shares one gather between 4 voxels: a NaN gate must poison the voxels it belongs to and no
+    others (compare with the CSR path, which has no blocking)."""
+    import torch
+    gx, gy, gz, val, mask = _cloud(5, 5000, extent=6e3, zmax=1e3)
+    val[int(np.argmin(gx * gx + gy * gy + (gz - 400.0) ** 2))] = np.nan     # a gate in reach of the grid, NOT masked
+    mask[:] = False
+    shape, limits = (1, 12, 80), ((400.0, 400.0), (-3e3, 3e3), (-5e3, 5e3))
+    o_ip, o_idx, o_w = oracle.build_geometry(gx, gy, gz, shape, limits, min_radius=700.0, beam_factor=0.0)
+    want = oracle.csr_apply(o_ip, o_idx, o_w, val, mask, shape)
+    search = rg.RoiSearch(gx, gy, gz, shape, limits, min_radius=700.0, beam_factor=0.0)
+    fused = rg.roi_grid_fields_device(search, [torch.from_numpy(val).to(search.dev)], [None])[0].cpu().numpy()
+    np.testing.assert_array_equal(np.isnan(fused), np.isnan(want))
+    assert 0 < np.isnan(fused).sum() < fused.size // 2
+    np.testing.assert_allclose(fused, want, rtol=1e-5, atol=6e-4, equal_nan=True)
