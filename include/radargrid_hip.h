@@ -197,7 +197,7 @@ int rg_geom_fill_f32(const rg_gate4* sorted_gates, const int32_t* cell_start, co
  * one kernel, no CSR in memory (for grids whose pair count makes the CSR pointless or impossible,
  * SURVEY.md F6).  Same neighbour sets and weights as the builder; results differ from the CSR path only by
  * float64 summation order.  `packed` is the rg_pack_fields_f32 layout over the same gate numbering as the
- * gates that were binned; gate indices must be < 2^28 (the kernel queues a 4-bit voxel mask above them).
+ * gates that were binned.
  * ------------------------------------------------------------------------------------------------- */
 int rg_roi_grid_f32(const rg_gate4* sorted_gates, const int32_t* cell_start, const rg_cellgrid* cells_host,
                     const float* xc, const float* yc, const float* zc, int32_t nz, int32_t ny, int32_t nx,

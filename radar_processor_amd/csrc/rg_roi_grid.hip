@@ -6,26 +6,24 @@
 // Bound: NOT HBM (compulsory traffic is only the sorted gates + packed fields + the output grid); the kernel is
 // limited by VALU issue for the candidate test and by the L1/L2-served loads of gate records.
 //
-// Structure (one wavefront = up to 64 consecutive voxels of ONE grid row, processed in groups of VB = 4):
-//   * lane l first computes voxel l's search box in the reference's float64 arithmetic (compute.py:46-47,57) --
-//     64 boxes for the price of one; the group loop then broadcasts them with readlane (SGPRs);
+// Structure (one wavefront = up to 64 consecutive voxels of ONE grid row, processed in blocks of 16):
 //   * voxel blocking: neighbouring voxels (240 m apart, ROI >= 250 m) share almost all candidates, so every gate
-//     record is loaded ONCE per group and tested against all VB voxels (y and z are common to the row, only x
-//     differs): 4x fewer loads, steps and gathers than one voxel at a time.  The kernel was latency-bound on the
-//     dependent chain cell_start -> gate record; the chain is broken by loading the bounds of all cell rows of
-//     the group with one vector load and by prefetching the next step's records before testing the current;
-//   * candidate test: 64 gates per step, one dwordx4 record each, float32 distance against a slightly INFLATED
-//     radius (r2 * (1 + 2e-6), rounded up): a conservative pre-filter that can only admit extra candidates;
-//   * survivors are compacted with ballot + mbcnt into a per-wave LDS ring together with a VB-bit mask of the
-//     voxels they may belong to; whenever 64 are queued, and at the end of the group, they are processed on
-//     DENSE lanes: exact float64 d2 per voxel and the reference's strict `d2 < r2` (compute.py:69-74) -- so the
-//     neighbour set equals the CSR builder's --, the weight (float32 exp; |rel err| < 1e-6), ONE gather from the
-//     packed fields shared by the VB voxels, masked accumulation;
-//   * per voxel a wavefront shuffle reduction of the lane partials; lane t keeps voxel t's result and the wave
-//     finishes with one coalesced 256-byte store per field.
+//     record is loaded ONCE per 16-voxel block.  The chain cell_start -> gate record that made the first version
+//     latency-bound is broken by loading the bounds of all cell rows of the block with one vector load and by
+//     prefetching the next step's records before testing the current ones;
+//   * candidate stage (lanes = 64 candidates per step, one dwordx4 record each): a float32 lower bound of the
+//     distance to the NEAREST voxel of the block (clamped x-distance to the block's extent; y and z are common)
+//     against the block's largest radius, inflated by 2e-6 -- a conservative pre-filter, ~17 VALU per 64
+//     candidates regardless of the block size; survivors are compacted with ballot + mbcnt into a per-wave LDS ring;
+//   * dense stage (lanes = 16 voxels x 4 queued records per step): lane k owns voxel k of the block -- its
+//     constants live in its registers, its sums never leave it -- and tests 4 records per step (LDS broadcast
+//     reads).  float32 d2 decides membership whenever it is clear of the rim by 2e-6; inside that band the lane
+//     falls back to the reference's exact float64 `d2 < r2` (compute.py:69-74), so the neighbour set equals the
+//     CSR builder's.  Weight in float32 (|rel err| < 2e-6), one gather per (record, voxel) hit served by L1;
+//   * per block two wavefront shuffles fold the 4 record slots; 16 lanes store 16 consecutive voxels per field.
 //
-// Compiled with -ffp-contract=off like every TU (the exact test must not be fused); the pre-filter uses explicit
-// fmaf, its error is covered by the inflation.
+// Compiled with -ffp-contract=off like every TU (the exact test must not be fused); the float32 tests use explicit
+// fmaf, their error is covered by the 2e-6 band.
 #include "rg_common.hpp"
 #include "rg_roi_search.hpp"
 
@@ -52,12 +50,6 @@ __device__ __forceinline__ void load_packed(const float* __restrict__ p, unsigne
   }
 }
 
-__device__ __forceinline__ float wave_sum_f32(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  return v;
-}
-
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
   const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
   const unsigned lo = __builtin_amdgcn_readlane((unsigned)b, lane);
@@ -65,24 +57,24 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
-// float32 weight from the exact float64 d2 / r2 (compute.py:82-87); relative error < 1e-6
+constexpr int kVB = 16;             // voxels per block (lane & 15)
+constexpr int kSlots = 64 / kVB;    // queued records tested per dense step (lane >> 4)
+
+// float32 weight from the float32 d2 (compute.py:82-87); relative error < 2e-6
 template <int W>
-__device__ __forceinline__ float weight_f32(double d2, double r2, float inv_r2q) {
+__device__ __forceinline__ float weight_from_f32(float d2f, float r2f, float inv_r2q) {
   if constexpr (W == RG_W_BARNES2) {
-    return __expf(-((float)d2 * inv_r2q)) + 1e-5f;
+    return __expf(-(d2f * inv_r2q)) + 1e-5f;
   } else if constexpr (W == RG_W_CRESSMAN) {
-    return (float)(r2 - d2) / (float)(r2 + d2);
+    return (r2f - d2f) / (r2f + d2f);
   } else {
     return 1.0f;
   }
 }
 
-constexpr int kMaskShift = 28;  // queue entries carry the voxel mask in the top bits of the gate index
-
-template <int W, int NF, int STRIDE, int VB>
+template <int W, int NF, int STRIDE>
 __global__ __launch_bounds__(rg::kBlock) void roi_grid_kernel(SearchArgs a, const float* __restrict__ packed, float fill,
                                                               float* __restrict__ out) {
-  static_assert(VB >= 1 && VB <= 4, "voxel mask has 4 bits");
   __shared__ rg_gate4 ring_all[rg::kBlock / rg::kWave][kRing];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -97,83 +89,61 @@ __global__ __launch_bounds__(rg::kBlock) void roi_grid_kernel(SearchArgs a, cons
   const double y = (double)a.yc[iy], z = (double)a.zc[iz];       // common to the whole wave
   const float yf = (float)y, zf = (float)z;                      // grid coordinates ARE float32 values: exact
   const long vbeg = grow * a.nx + ix0;
+  const int vl = lane & (kVB - 1);                               // voxel of the block this lane owns
+  const int slot = lane >> 4;                                    // which of the 4 records of a dense step
 
-  // ---- 64 search boxes at once: lane l <-> voxel ix0 + l ----------------------------------------------
-  double bx, br2;
-  int bcx0, bcx1, bcy0, bcy1;
-  {
-    bx = (double)a.xc[ix0 + (lane < n_here ? lane : 0)];
-    const double dist = sqrt(bx * bx + y * y + z * z);           // compute.py:46
-    const double r = fmax(a.min_radius, dist * a.beam_factor);   // compute.py:47
-    br2 = r * r;                                                 // compute.py:57
-    bcx0 = cell_clamped(bx - r, a.c.x0, a.c.inv_cx, a.c.ncx);
-    bcx1 = cell_clamped(bx + r, a.c.x0, a.c.inv_cx, a.c.ncx);
-    bcy0 = cell_clamped(y - r, a.c.y0, a.c.inv_cy, a.c.ncy);
-    bcy1 = cell_clamped(y + r, a.c.y0, a.c.inv_cy, a.c.ncy);
-  }
+  for (int b0 = 0; b0 < n_here; b0 += kVB) {
+    const int nv = n_here - b0 < kVB ? n_here - b0 : kVB;        // wave-uniform
+    const bool vlive = vl < nv;
+    // ---- this lane's voxel: the reference's float64 ROI (compute.py:46-47,57) and its float32 bounds --------
+    const double x = (double)a.xc[ix0 + b0 + (vlive ? vl : 0)];
+    const double dist = sqrt(x * x + y * y + z * z);
+    const double r = fmax(a.min_radius, dist * a.beam_factor);
+    const double r2 = r * r;
+    const float xf = (float)x, r2f = (float)r2;
+    // float32 d2 carries < 4e-7 relative error: outside [r2_lo, r2_hi] the float32 comparison is already exact
+    const float r2_hi = vlive ? (float)(r2 * (1.0 + 2e-6)) * (1.0f + 2.4e-7f) : -1.0f;
+    const float r2_lo = (float)(r2 * (1.0 - 2e-6)) * (1.0f - 2.4e-7f);
+    const float inv_r2q = (float)(4.0 / r2);
+    // ---- block-wide (wave-uniform) quantities ------------------------------------------------------------
+    double rmax = vlive ? r : 0.0;
+#pragma unroll
+    for (int m = 1; m < kVB; m <<= 1) rmax = fmax(rmax, __shfl_xor(rmax, m, 64));
+    rmax = readlane_f64(rmax, 0);
+    const float xa = a.xc[ix0 + b0], xb = a.xc[ix0 + b0 + nv - 1];
+    const float xlo = fminf(xa, xb), xhi = fmaxf(xa, xb);
+    const float r2max_hi = (float)(rmax * rmax * (1.0 + 2e-6)) * (1.0f + 2.4e-7f);
+    const int cx0 = __builtin_amdgcn_readfirstlane(cell_clamped((double)xlo - rmax, a.c.x0, a.c.inv_cx, a.c.ncx));
+    const int cx1 = __builtin_amdgcn_readfirstlane(cell_clamped((double)xhi + rmax, a.c.x0, a.c.inv_cx, a.c.ncx));
+    const int cy0 = __builtin_amdgcn_readfirstlane(cell_clamped(y - rmax, a.c.y0, a.c.inv_cy, a.c.ncy));
+    const int cy1 = __builtin_amdgcn_readfirstlane(cell_clamped(y + rmax, a.c.y0, a.c.inv_cy, a.c.ncy));
 
-  float my_res[NF];
+    float acc_p[NF], acc_w[NF];
 #pragma unroll
-  for (int f = 0; f < NF; ++f) my_res[f] = fill;
-
-  for (int g0 = 0; g0 < n_here; g0 += VB) {
-    const int nv = n_here - g0 < VB ? n_here - g0 : VB;  // wave-uniform
-    // per-voxel constants of the group (SGPRs) and the union of the VB search boxes
-    double xk[VB], r2k[VB];
-    float xfk[VB], r2hik[VB], iqk[VB];
-    int cx0 = 0x7FFFFFFF, cx1 = -1, cy0 = 0x7FFFFFFF, cy1 = -1;
-#pragma unroll
-    for (int k = 0; k < VB; ++k) {
-      const int src = g0 + (k < nv ? k : 0);
-      xk[k] = readlane_f64(bx, src);
-      r2k[k] = readlane_f64(br2, src);
-      xfk[k] = (float)xk[k];
-      // inflated float32 radius: fl32 distance error < 4e-7 relative, r2 -> float rounding 6e-8
-      r2hik[k] = k < nv ? (float)(r2k[k] * (1.0 + 2e-6)) * (1.0f + 2.4e-7f) : -1.0f;
-      iqk[k] = (float)(4.0 / r2k[k]);
-      const int a0 = __builtin_amdgcn_readlane(bcx0, src), a1 = __builtin_amdgcn_readlane(bcx1, src);
-      const int b0 = __builtin_amdgcn_readlane(bcy0, src), b1 = __builtin_amdgcn_readlane(bcy1, src);
-      cx0 = a0 < cx0 ? a0 : cx0; cx1 = a1 > cx1 ? a1 : cx1;
-      cy0 = b0 < cy0 ? b0 : cy0; cy1 = b1 > cy1 ? b1 : cy1;
-    }
-
-    float acc_p[VB][NF], acc_w[VB][NF];
-#pragma unroll
-    for (int k = 0; k < VB; ++k)
-#pragma unroll
-      for (int f = 0; f < NF; ++f) { acc_p[k][f] = 0.0f; acc_w[k][f] = 0.0f; }
+    for (int f = 0; f < NF; ++f) { acc_p[f] = 0.0f; acc_w[f] = 0.0f; }
     int head = 0, tail = 0;  // ring positions (wave-uniform, monotone)
 
-    auto process = [&](int n) {  // n <= 64 queued candidates on dense lanes
-      if (lane < n) {
-        const rg_gate4 g = ring[(head + lane) & (kRing - 1)];
-        const unsigned mask = (unsigned)g.index >> kMaskShift;
-        const unsigned gate = (unsigned)g.index & ((1u << kMaskShift) - 1);
-        const double gx = (double)g.x;
-        const double dy = (double)g.y - y, dz = (double)g.z - z;   // compute.py:70-71
-        const double dy2 = dy * dy, dz2 = dz * dz;
-        float w[VB];
-        bool any = false;
+    auto dense = [&](int n) {  // test n queued records against the 16 voxels, 4 records per step
+      for (int e0 = 0; e0 < n; e0 += kSlots) {
+        const int e = e0 + slot;
+        if (e < n) {
+          const rg_gate4 g = ring[(head + e) & (kRing - 1)];
+          const float dx = g.x - xf, dy = g.y - yf, dz = g.z - zf;
+          const float d2f = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+          bool in = d2f <= r2_lo;
+          if (!in && d2f <= r2_hi) {  // within 2e-6 of the rim: the reference's float64 arithmetic decides
+            const double ex = (double)g.x - x, ey = (double)g.y - y, ez = (double)g.z - z;  // compute.py:69-71
+            in = ex * ex + ey * ey + ez * ez < r2;                                          // compute.py:72,74
+          }
+          if (in) {
+            const float w = weight_from_f32<W>(d2f, r2f, inv_r2q);
+            float val[STRIDE];
+            load_packed<STRIDE>(packed, (unsigned)g.index, val);
 #pragma unroll
-        for (int k = 0; k < VB; ++k) {
-          const double dx = gx - xk[k];                            // compute.py:69
-          const double d2 = dx * dx + dy2 + dz2;                   // compute.py:72, same association
-          const bool in = ((mask >> k) & 1u) != 0 && d2 < r2k[k];  // compute.py:74
-          w[k] = in ? weight_f32<W>(d2, r2k[k], iqk[k]) : 0.0f;
-          any = any || in;
-        }
-        if (any) {
-          float val[STRIDE];
-          load_packed<STRIDE>(packed, gate, val);
-#pragma unroll
-          for (int f = 0; f < NF; ++f) {
-            const bool ok = rg::f32_bits(val[f]) != RG_EXCLUDED_BITS;
-            const float v = ok ? val[f] : 0.0f;
-#pragma unroll
-            for (int k = 0; k < VB; ++k) {
-              // w[k] > 0 <=> the gate is a neighbour of voxel k; an unmasked NaN/Inf value must only reach those
-              acc_p[k][f] += w[k] > 0.0f ? w[k] * v : 0.0f;         // float32 product, as interpolate.py:82
-              acc_w[k][f] += ok ? w[k] : 0.0f;
+            for (int f = 0; f < NF; ++f) {
+              const bool ok = rg::f32_bits(val[f]) != RG_EXCLUDED_BITS;
+              acc_p[f] += ok ? w * val[f] : 0.0f;  // float32 product, as interpolate.py:82
+              acc_w[f] += ok ? w : 0.0f;
             }
           }
         }
@@ -211,55 +181,41 @@ __global__ __launch_bounds__(rg::kBlock) void roi_grid_kernel(SearchArgs a, cons
         const bool valid = vn;
         have = advance();
         if (have) { vn = jb + lane < je; if (vn) gn = a.sorted[jb + lane]; }  // prefetch the next step
-        // float32 pre-filter against all VB voxels of the group (y, z shared)
+        // lower bound of the distance to the nearest voxel of the block vs the block's largest (inflated) radius
         const float dy = g.y - yf, dz = g.z - zf;
-        const float dyz2 = __builtin_fmaf(dz, dz, dy * dy);
-        unsigned mask = 0;
-#pragma unroll
-        for (int k = 0; k < VB; ++k) {
-          const float dx = g.x - xfk[k];
-          mask |= (__builtin_fmaf(dx, dx, dyz2) <= r2hik[k] ? 1u : 0u) << k;
-        }
-        const bool pre = valid && mask != 0;
+        const float dxb = fmaxf(fmaxf(xlo - g.x, g.x - xhi), 0.0f);
+        const float d2min = __builtin_fmaf(dxb, dxb, __builtin_fmaf(dz, dz, dy * dy));
+        const bool pre = valid && d2min <= r2max_hi;
         const unsigned long long m = __ballot(pre);
         if (pre) {
           const int pos = tail + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-          rg_gate4 q = g;
-          q.index = (int)((unsigned)g.index | (mask << kMaskShift));
-          ring[pos & (kRing - 1)] = q;
+          ring[pos & (kRing - 1)] = g;
         }
         tail += __popcll(m);
         if (tail - head >= 64) {
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          process(64);
+          dense(64);
         }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    process(tail - head);
+    dense(tail - head);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+    // ---- fold the 4 record slots; lanes 0..15 hold the block's 16 voxels ----------------------------------
 #pragma unroll
-    for (int k = 0; k < VB; ++k) {
-#pragma unroll
-      for (int f = 0; f < NF; ++f) {
-        const float p = wave_sum_f32(acc_p[k][f]);
-        const float w = wave_sum_f32(acc_w[k][f]);
-        const float r = w > 0.0f ? (float)((double)p / (double)w) : fill;
-        if (k < nv && lane == g0 + k) my_res[f] = r;
-      }
+    for (int f = 0; f < NF; ++f) {
+      float p = acc_p[f], w = acc_w[f];
+      p += __shfl_xor(p, 16, 64); w += __shfl_xor(w, 16, 64);
+      p += __shfl_xor(p, 32, 64); w += __shfl_xor(w, 32, 64);
+      if (slot == 0 && vlive) out[(size_t)f * a.n_vox + vbeg + b0 + vl] = w > 0.0f ? (float)((double)p / (double)w) : fill;
     }
-  }
-
-  if (lane < n_here) {
-#pragma unroll
-    for (int f = 0; f < NF; ++f) out[(size_t)f * a.n_vox + vbeg + lane] = my_res[f];
   }
 }
 
@@ -271,8 +227,7 @@ inline dim3 k2_grid(const SearchArgs& a) {
 
 template <int W, int NF, int STRIDE>
 int launch(const SearchArgs& a, const float* packed, float fill, float* out, hipStream_t s) {
-  constexpr int VB = NF <= 4 ? 4 : 2;   // accumulator registers: 2 * VB * NF
-  hipLaunchKernelGGL((roi_grid_kernel<W, NF, STRIDE, VB>), k2_grid(a), dim3(rg::kBlock), 0, s, a, packed, fill, out);
+  hipLaunchKernelGGL((roi_grid_kernel<W, NF, STRIDE>), k2_grid(a), dim3(rg::kBlock), 0, s, a, packed, fill, out);
   return rg::check_launch("rg_roi_grid_f32");
 }
 

@@ -31,8 +31,6 @@ def roi_grid_fields_device(search: RoiSearch, fields: Sequence, masks: Optional[
         raise ValueError("no fields to grid")
     dev = search.dev
     n_gates = search.n_gates
-    if n_gates >= 1 << 28:
-        raise ValueError("the fused gridder packs a 4-bit voxel mask above the gate index: n_gates must be < 2**28")
     for i, f in enumerate(fields):
         if not (f.is_cuda and f.dtype == torch.float32 and f.is_contiguous() and f.numel() == n_gates):
             raise ValueError(f"field {i}: expected a contiguous cuda float32 tensor of {n_gates} gates")
