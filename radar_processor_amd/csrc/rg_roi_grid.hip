@@ -57,8 +57,6 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
-constexpr int kVB = 16;             // voxels per block (lane & 15)
-constexpr int kSlots = 64 / kVB;    // queued records tested per dense step (lane >> 4)
 
 // float32 weight from the float32 d2 (compute.py:82-87); relative error < 2e-6
 template <int W>
@@ -72,9 +70,11 @@ __device__ __forceinline__ float weight_from_f32(float d2f, float r2f, float inv
   }
 }
 
-template <int W, int NF, int STRIDE>
+template <int W, int NF, int STRIDE, int kVB>
 __global__ __launch_bounds__(rg::kBlock) void roi_grid_kernel(SearchArgs a, const float* __restrict__ packed, float fill,
                                                               float* __restrict__ out) {
+  constexpr int kSlots = 64 / kVB;    // queued records tested per dense step
+  constexpr int kLgVB = kVB == 8 ? 3 : kVB == 16 ? 4 : 5;
   __shared__ rg_gate4 ring_all[rg::kBlock / rg::kWave][kRing];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(rg::kBlock) void roi_grid_kernel(SearchArgs a, cons
   const float yf = (float)y, zf = (float)z;                      // grid coordinates ARE float32 values: exact
   const long vbeg = grow * a.nx + ix0;
   const int vl = lane & (kVB - 1);                               // voxel of the block this lane owns
-  const int slot = lane >> 4;                                    // which of the 4 records of a dense step
+  const int slot = lane >> kLgVB;                                // which of the records of a dense step
 
   for (int b0 = 0; b0 < n_here; b0 += kVB) {
     const int nv = n_here - b0 < kVB ? n_here - b0 : kVB;        // wave-uniform
@@ -212,8 +212,8 @@ __global__ __launch_bounds__(rg::kBlock) void roi_grid_kernel(SearchArgs a, cons
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
       float p = acc_p[f], w = acc_w[f];
-      p += __shfl_xor(p, 16, 64); w += __shfl_xor(w, 16, 64);
-      p += __shfl_xor(p, 32, 64); w += __shfl_xor(w, 32, 64);
+#pragma unroll
+      for (int m = kVB; m < 64; m <<= 1) { p += __shfl_xor(p, m, 64); w += __shfl_xor(w, m, 64); }
       if (slot == 0 && vlive) out[(size_t)f * a.n_vox + vbeg + b0 + vl] = w > 0.0f ? (float)((double)p / (double)w) : fill;
     }
   }
@@ -227,7 +227,8 @@ inline dim3 k2_grid(const SearchArgs& a) {
 
 template <int W, int NF, int STRIDE>
 int launch(const SearchArgs& a, const float* packed, float fill, float* out, hipStream_t s) {
-  hipLaunchKernelGGL((roi_grid_kernel<W, NF, STRIDE>), k2_grid(a), dim3(rg::kBlock), 0, s, a, packed, fill, out);
+  // voxel-block size 16: measured 18.9 ms on the bench grid against 22.6 (8) and 20.5 (32)
+  hipLaunchKernelGGL((roi_grid_kernel<W, NF, STRIDE, 16>), k2_grid(a), dim3(rg::kBlock), 0, s, a, packed, fill, out);
   return rg::check_launch("rg_roi_grid_f32");
 }
 

@@ -6,6 +6,7 @@ set -u
 TAG=${1:-r01}; shift || true
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_${TAG}
+rm -rf "$OUT"
 mkdir -p "$OUT"
 ARGS="--steps 5 --warmup 1 --no-cpu-baseline $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py $ARGS > "$OUT/trace_bench.json" 2> "$OUT/trace.log" || exit 1
