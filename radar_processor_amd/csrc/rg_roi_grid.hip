@@ -6,13 +6,13 @@
 // Bound: NOT HBM (compulsory traffic is only the sorted gates + packed fields + the output grid); the kernel is
 // limited by VALU issue for the candidate test and by the L1/L2-served loads of gate records.
 //
-// Structure (one wavefront = up to 64 consecutive voxels of ONE grid row, processed in blocks of 16):
+// Structure (one wavefront = a 32 x 2 patch of one grid level, processed as 4 blocks of 8 x 2 = 16 voxels):
 //   * voxel blocking: neighbouring voxels (240 m apart, ROI >= 250 m) share almost all candidates, so every gate
 //     record is loaded ONCE per 16-voxel block.  The chain cell_start -> gate record that made the first version
 //     latency-bound is broken by loading the bounds of all cell rows of the block with one vector load and by
 //     prefetching the next step's records before testing the current ones;
 //   * candidate stage (lanes = 64 candidates per step, one dwordx4 record each): a float32 lower bound of the
-//     distance to the NEAREST voxel of the block (clamped x-distance to the block's extent; y and z are common)
+//     distance to the NEAREST voxel of the block (clamped x- and y-distances to the block's extent; z is common)
 //     against the block's largest radius, inflated by 2e-6 -- a conservative pre-filter, ~17 VALU per 64
 //     candidates regardless of the block size; survivors are compacted with ballot + mbcnt into a per-wave LDS ring;
 //   * dense stage (lanes = 16 voxels x 4 queued records per step): lane k owns voxel k of the block -- its
@@ -31,7 +31,6 @@ namespace {
 
 using namespace rg::roi;
 
-constexpr int kVoxPerWaveK2 = 64;
 constexpr int kRing = 128;  // queue slots per wave (power of two, >= 2 * 64)
 
 template <int STRIDE>
@@ -70,37 +69,45 @@ __device__ __forceinline__ float weight_from_f32(float d2f, float r2f, float inv
   }
 }
 
-template <int W, int NF, int STRIDE, int kVB>
+// BX x BY = 16 voxels per block (BY rows of BX consecutive voxels); a wavefront walks 4 blocks side by side in x.
+template <int W, int NF, int STRIDE, int BX>
 __global__ __launch_bounds__(rg::kBlock) void roi_grid_kernel(SearchArgs a, const float* __restrict__ packed, float fill,
                                                               float* __restrict__ out) {
+  constexpr int kVB = 16;             // voxels per block
+  constexpr int BY = kVB / BX;
+  constexpr int PX = 4 * BX;          // patch of one wavefront: PX x BY voxels of one level
   constexpr int kSlots = 64 / kVB;    // queued records tested per dense step
-  constexpr int kLgVB = kVB == 8 ? 3 : kVB == 16 ? 4 : 5;
+  constexpr int kLgBX = BX == 16 ? 4 : BX == 8 ? 3 : 2;
   __shared__ rg_gate4 ring_all[rg::kBlock / rg::kWave][kRing];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   rg_gate4* ring = ring_all[wv];
-  const int wpr = (a.nx + kVoxPerWaveK2 - 1) / kVoxPerWaveK2;  // waves per grid row
+  const long wpx = (a.nx + PX - 1) / PX, wpy = (a.ny + BY - 1) / BY;   // patches per level
   const long wave = (long)blockIdx.x * (rg::kBlock / rg::kWave) + wv;
-  const long grow = wave / wpr;                                  // grid row = iz * ny + iy
-  if (grow >= (long)a.nz * a.ny) return;                         // wave-uniform
-  const int ix0 = (int)(wave - grow * wpr) * kVoxPerWaveK2;
-  const int n_here = a.nx - ix0 < kVoxPerWaveK2 ? a.nx - ix0 : kVoxPerWaveK2;
-  const int iy = (int)(grow % a.ny), iz = (int)(grow / a.ny);
-  const double y = (double)a.yc[iy], z = (double)a.zc[iz];       // common to the whole wave
-  const float yf = (float)y, zf = (float)z;                      // grid coordinates ARE float32 values: exact
-  const long vbeg = grow * a.nx + ix0;
-  const int vl = lane & (kVB - 1);                               // voxel of the block this lane owns
-  const int slot = lane >> kLgVB;                                // which of the records of a dense step
+  const long iz_l = wave / (wpx * wpy);
+  if (iz_l >= a.nz) return;                                      // wave-uniform
+  const long rem = wave - iz_l * (wpx * wpy);
+  const int iz = (int)iz_l;
+  const int iy0 = (int)(rem / wpx) * BY, ix0 = (int)(rem % wpx) * PX;
+  const int nvy = a.ny - iy0 < BY ? a.ny - iy0 : BY;
+  const double z = (double)a.zc[iz];                             // common to the whole wave
+  const float zf = (float)z;                                     // grid coordinates ARE float32 values: exact
+  const int vl = lane & (kVB - 1);                               // voxel of the block this lane owns ...
+  const int bxl = vl & (BX - 1), byl = vl >> kLgBX;              // ... at (bxl, byl) inside the block
+  const int slot = lane >> 4;                                    // which of the 4 records of a dense step
+  const float ya = a.yc[iy0], yb = a.yc[iy0 + nvy - 1];
+  const float ylo = fminf(ya, yb), yhi = fmaxf(ya, yb);
 
-  for (int b0 = 0; b0 < n_here; b0 += kVB) {
-    const int nv = n_here - b0 < kVB ? n_here - b0 : kVB;        // wave-uniform
-    const bool vlive = vl < nv;
+  for (int b0 = 0; b0 < PX && ix0 + b0 < a.nx; b0 += BX) {
+    const int nvx = a.nx - ix0 - b0 < BX ? a.nx - ix0 - b0 : BX;  // wave-uniform
+    const bool vlive = bxl < nvx && byl < nvy;
     // ---- this lane's voxel: the reference's float64 ROI (compute.py:46-47,57) and its float32 bounds --------
-    const double x = (double)a.xc[ix0 + b0 + (vlive ? vl : 0)];
+    const double x = (double)a.xc[ix0 + b0 + (vlive ? bxl : 0)];
+    const double y = (double)a.yc[iy0 + (vlive ? byl : 0)];
     const double dist = sqrt(x * x + y * y + z * z);
     const double r = fmax(a.min_radius, dist * a.beam_factor);
     const double r2 = r * r;
-    const float xf = (float)x, r2f = (float)r2;
+    const float xf = (float)x, yf = (float)y, r2f = (float)r2;
     // float32 d2 carries < 4e-7 relative error: outside [r2_lo, r2_hi] the float32 comparison is already exact
     const float r2_hi = vlive ? (float)(r2 * (1.0 + 2e-6)) * (1.0f + 2.4e-7f) : -1.0f;
     const float r2_lo = (float)(r2 * (1.0 - 2e-6)) * (1.0f - 2.4e-7f);
@@ -110,20 +117,20 @@ __global__ __launch_bounds__(rg::kBlock) void roi_grid_kernel(SearchArgs a, cons
 #pragma unroll
     for (int m = 1; m < kVB; m <<= 1) rmax = fmax(rmax, __shfl_xor(rmax, m, 64));
     rmax = readlane_f64(rmax, 0);
-    const float xa = a.xc[ix0 + b0], xb = a.xc[ix0 + b0 + nv - 1];
+    const float xa = a.xc[ix0 + b0], xb = a.xc[ix0 + b0 + nvx - 1];
     const float xlo = fminf(xa, xb), xhi = fmaxf(xa, xb);
     const float r2max_hi = (float)(rmax * rmax * (1.0 + 2e-6)) * (1.0f + 2.4e-7f);
     const int cx0 = __builtin_amdgcn_readfirstlane(cell_clamped((double)xlo - rmax, a.c.x0, a.c.inv_cx, a.c.ncx));
     const int cx1 = __builtin_amdgcn_readfirstlane(cell_clamped((double)xhi + rmax, a.c.x0, a.c.inv_cx, a.c.ncx));
-    const int cy0 = __builtin_amdgcn_readfirstlane(cell_clamped(y - rmax, a.c.y0, a.c.inv_cy, a.c.ncy));
-    const int cy1 = __builtin_amdgcn_readfirstlane(cell_clamped(y + rmax, a.c.y0, a.c.inv_cy, a.c.ncy));
+    const int cy0 = __builtin_amdgcn_readfirstlane(cell_clamped((double)ylo - rmax, a.c.y0, a.c.inv_cy, a.c.ncy));
+    const int cy1 = __builtin_amdgcn_readfirstlane(cell_clamped((double)yhi + rmax, a.c.y0, a.c.inv_cy, a.c.ncy));
 
     float acc_p[NF], acc_w[NF];
 #pragma unroll
     for (int f = 0; f < NF; ++f) { acc_p[f] = 0.0f; acc_w[f] = 0.0f; }
     int head = 0, tail = 0;  // ring positions (wave-uniform, monotone)
 
-    auto dense = [&](int n) {  // test n queued records against the 16 voxels, 4 records per step
+    auto dense = [&](int n) {  // test n queued records against the block's 16 voxels, 4 records per step
       for (int e0 = 0; e0 < n; e0 += kSlots) {
         const int e = e0 + slot;
         if (e < n) {
@@ -182,9 +189,10 @@ __global__ __launch_bounds__(rg::kBlock) void roi_grid_kernel(SearchArgs a, cons
         have = advance();
         if (have) { vn = jb + lane < je; if (vn) gn = a.sorted[jb + lane]; }  // prefetch the next step
         // lower bound of the distance to the nearest voxel of the block vs the block's largest (inflated) radius
-        const float dy = g.y - yf, dz = g.z - zf;
+        const float dz = g.z - zf;
         const float dxb = fmaxf(fmaxf(xlo - g.x, g.x - xhi), 0.0f);
-        const float d2min = __builtin_fmaf(dxb, dxb, __builtin_fmaf(dz, dz, dy * dy));
+        const float dyb = fmaxf(fmaxf(ylo - g.y, g.y - yhi), 0.0f);
+        const float d2min = __builtin_fmaf(dxb, dxb, __builtin_fmaf(dyb, dyb, dz * dz));
         const bool pre = valid && d2min <= r2max_hi;
         const unsigned long long m = __ballot(pre);
         if (pre) {
@@ -214,21 +222,25 @@ __global__ __launch_bounds__(rg::kBlock) void roi_grid_kernel(SearchArgs a, cons
       float p = acc_p[f], w = acc_w[f];
 #pragma unroll
       for (int m = kVB; m < 64; m <<= 1) { p += __shfl_xor(p, m, 64); w += __shfl_xor(w, m, 64); }
-      if (slot == 0 && vlive) out[(size_t)f * a.n_vox + vbeg + b0 + vl] = w > 0.0f ? (float)((double)p / (double)w) : fill;
+      if (slot == 0 && vlive) {
+        const size_t v = ((size_t)iz * a.ny + (iy0 + byl)) * a.nx + (ix0 + b0 + bxl);
+        out[(size_t)f * a.n_vox + v] = w > 0.0f ? (float)((double)p / (double)w) : fill;
+      }
     }
   }
 }
 
+template <int BX>
 inline dim3 k2_grid(const SearchArgs& a) {
-  const long wpr = (a.nx + kVoxPerWaveK2 - 1) / kVoxPerWaveK2;
-  const long waves = wpr * a.ny * a.nz;
+  constexpr int BY = 16 / BX, PX = 4 * BX;
+  const long waves = (long)((a.nx + PX - 1) / PX) * ((a.ny + BY - 1) / BY) * a.nz;
   return dim3((unsigned)((waves + 3) / 4));
 }
 
 template <int W, int NF, int STRIDE>
 int launch(const SearchArgs& a, const float* packed, float fill, float* out, hipStream_t s) {
-  // voxel-block size 16: measured 18.9 ms on the bench grid against 22.6 (8) and 20.5 (32)
-  hipLaunchKernelGGL((roi_grid_kernel<W, NF, STRIDE, 16>), k2_grid(a), dim3(rg::kBlock), 0, s, a, packed, fill, out);
+  // block shape 8 x 2: measured 16.0 ms on the bench grid against 16.5 (4 x 4) and 19.4 (16 x 1)
+  hipLaunchKernelGGL((roi_grid_kernel<W, NF, STRIDE, 8>), k2_grid<8>(a), dim3(rg::kBlock), 0, s, a, packed, fill, out);
   return rg::check_launch("rg_roi_grid_f32");
 }
 
@@ -264,7 +276,7 @@ extern "C" int rg_roi_grid_f32(const rg_gate4* sorted_gates, const int32_t* cell
   RG_REQUIRE(stride == stride_for(n_fields), RG_EINVAL, "rg_roi_grid_f32: stride=%d, expected %d for %d fields", stride,
              stride_for(n_fields), n_fields);
   RG_REQUIRE(rg::aligned16(packed), RG_EALIGN, "rg_roi_grid_f32: packed must be 16-byte aligned");
-  RG_REQUIRE((long)nx * ny * nz > 0 && (long)((nx + 63) / 64) * ny * nz < 0x3FFFFFFFFL, RG_EUNSUPPORTED,
+  RG_REQUIRE((long)nx * ny * nz > 0 && (long)((nx + 15) / 16) * ny * nz < 0x3FFFFFFFFL, RG_EUNSUPPORTED,
              "rg_roi_grid_f32: grid too large for one launch");
   const SearchArgs a = make_args(sorted_gates, cell_start, cells_host, xc, yc, zc, nz, ny, nx, min_radius, beam_factor);
   hipStream_t s = (hipStream_t)stream;
