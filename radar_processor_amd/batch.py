@@ -105,17 +105,23 @@ def gather_results(local: Dict[int, object], n_items: int, dst: int = 0, group=N
 
 class VolumeBatch:
     """Grids this rank's shard of a batch of volumes through one shared geometry, fusing up to 8 field-volumes
-    into each CSR pass (the CSR is the dominant HBM traffic, so it is read once for the whole group).
+    into each pass (the CSR -- or, for the CSR-free gridder, the candidate search -- is the dominant cost, so it is
+    paid once for the whole group).
 
+    ``geometry``: a :class:`GridGeometry` (CSR path, ``rg_csr_apply_f32``) or a :class:`RoiSearch` (fused path,
+    ``rg_roi_grid_f32``; measured faster than the CSR path as soon as 3 or more field-volumes share a pass).
     ``volumes``: sequence of ``{field name: (values, mask)}`` per volume, values float32 ``[G]`` and mask
     uint8/bool ``[G]`` or ``None`` -- NumPy arrays or tensors already on the device.
     """
 
-    def __init__(self, geometry, field_names: Sequence[str], device=None):
+    def __init__(self, geometry, field_names: Sequence[str], device=None, weighting: str = "barnes2"):
         from . import _native
+        from .geometry_builder import RoiSearch
         self.geometry = geometry
+        self.fused = isinstance(geometry, RoiSearch)
+        self.weighting = weighting
         self.field_names = list(field_names)
-        self.dev = _native.device() if device is None else device
+        self.dev = geometry.dev if self.fused else (_native.device() if device is None else device)
         if not 1 <= len(self.field_names) <= _native.RG_MAX_FIELDS:
             raise ValueError("1..8 fields per volume")
         self.volumes_per_pass = max(1, _native.RG_MAX_FIELDS // len(self.field_names))
@@ -134,6 +140,7 @@ class VolumeBatch:
         given, so that only 2-D planes outlive the pass."""
         import torch
         from .gridding import grid_fields_device
+        from .roi_grid import roi_grid_fields_device
         mine = shard_indices(len(volumes), rank, world_size)
         out: Dict[int, object] = {}
         n_f = len(self.field_names)
@@ -145,7 +152,10 @@ class VolumeBatch:
                     values, mask = volumes[b][name]
                     fields.append(self._to_dev(values, torch.float32))
                     masks.append(self._to_dev(mask, torch.uint8))
-            grids = grid_fields_device(self.geometry, fields, masks)
+            if self.fused:
+                grids = roi_grid_fields_device(self.geometry, fields, masks, weighting=self.weighting)
+            else:
+                grids = grid_fields_device(self.geometry, fields, masks)
             for i, b in enumerate(group):
                 g = grids[i * n_f:(i + 1) * n_f]
                 out[b] = products(g) if products is not None else g

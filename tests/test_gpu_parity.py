@@ -382,6 +382,14 @@ def test_volume_batch_fuses_passes(rg):
     # a different fused-field count uses a different tile size, i.e. another float32 partial-sum grouping
     np.testing.assert_allclose(grids[0][0].cpu().numpy(), rg.apply_geometry(geom, vols[0].fields["DBZH"]),
                                rtol=1e-6, atol=1e-5, equal_nan=True)
+    # the same batch through the CSR-free gridder (RoiSearch instead of a GridGeometry)
+    shape, limits = grid_spec(meta)
+    vbf = batch.VolumeBatch(rg.RoiSearch(vols[0].gate_x, vols[0].gate_y, vols[0].gate_z, shape, limits), names)
+    fused = vbf.grid_shard(payload)
+    for b in range(len(vols)):
+        for i in range(len(names)):
+            np.testing.assert_allclose(fused[b][i].cpu().numpy(), grids[b][i].cpu().numpy(), rtol=1e-5, atol=1e-3,
+                                       equal_nan=True)
     planes = vb.grid_shard(payload, products=lambda g: rg.column_max(g[0]).cpu().numpy(), rank=1, world_size=2)
     assert sorted(planes) == [1, 3]
     np.testing.assert_array_equal(planes[3], oracle.column_max(grids[3][0].cpu().numpy(), 0, 19))
