@@ -185,7 +185,8 @@ def main():
         algo_bytes = (12 + 5 * n_ff) * n_gates + 4 * n_ff * n_vox
         kernel_name = "roi_grid_kernel"
     torch.cuda.synchronize()
-    log(f"rank {rank}: geometry ({args.mode}) ready in {time.perf_counter() - t0:.1f}s"
+    t_geom = time.perf_counter() - t0
+    log(f"rank {rank}: geometry ({args.mode}) ready in {t_geom:.1f}s"
         + (f": {n_pairs:,} pairs ({n_pairs / n_vox:.1f}/voxel), {algo_bytes / 1e9:.2f} GB algorithmic per launch" if n_pairs else ""))
 
     grid4 = out.view(n_ff, *shape)
@@ -266,6 +267,26 @@ def main():
                 "kernel_ms": round(kernel_ms, 4),
             },
         }
+        if n_gpus == 1 and args.mode == "csr":
+            # side measurement on the same inputs (not part of `value`): the CSR-free fused gridder (K2)
+            try:
+                from radar_processor_amd.roi_grid import roi_grid_fields_device
+                search = rg.RoiSearch(vol.gate_x, vol.gate_y, vol.gate_z, shape, limits, device=dev)
+                roi_grid_fields_device(search, fields_d, masks_d, shared_mask=shared, out=grid4)
+                a_ev, b_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a_ev.record()
+                for _ in range(3):
+                    roi_grid_fields_device(search, fields_d, masks_d, shared_mask=shared, out=grid4)
+                b_ev.record()
+                b_ev.synchronize()
+                k2_ms = a_ev.elapsed_time(b_ev) / 3
+                result["extras"] = {"geometry_build_s": round(t_geom, 3),
+                                    "roi_grid_fused_ms": round(k2_ms, 3),
+                                    "roi_grid_fused_mvoxel_s": round(n_ff * n_vox / k2_ms / 1e3, 1),
+                                    "note": "rg_roi_grid_f32: same volume gridded without a CSR (search fused in)"}
+                del search
+            except Exception as exc:
+                log(f"fused side measurement failed: {exc!r}")
         if n_gpus == 1 and not args.no_cpu_baseline and args.mode == "csr":
             log("timing the CPU baseline (NumPy port, 1 core) on a bounded sample ...")
             try:
