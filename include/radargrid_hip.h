@@ -162,7 +162,11 @@ typedef struct rg_cellgrid {
 
 typedef struct rg_gate4 { float x, y, z; int32_t index; } rg_gate4; /* 16 bytes: one dwordx4 per candidate */
 
-typedef enum rg_weighting { RG_W_BARNES2 = 0, RG_W_CRESSMAN = 1, RG_W_NEAREST = 2 } rg_weighting;
+/* RG_W_NEAREST is the reference's 'nearest' = uniform mean over the ROI (radar_grid/compute.py:86-87).
+ * RG_W_CLOSEST (rg_roi_grid_f32 only) takes the value of the single closest non-excluded gate inside the ROI -- the
+ * selection rule of PyART's map_gates_to_grid(weighting_function='nearest') that radar_processor/processor.py:152-163
+ * uses behind the 3-D grid cache; PyART is not in the reference tree, so this mode is parity-unpinned. */
+typedef enum rg_weighting { RG_W_BARNES2 = 0, RG_W_CRESSMAN = 1, RG_W_NEAREST = 2, RG_W_CLOSEST = 3 } rg_weighting;
 
 /* bytes of scratch rg_geom_bin_gates_f32 needs for n_gates gates */
 int64_t rg_geom_bin_workspace_bytes(int64_t n_gates, int32_t ncx, int32_t ncy);

@@ -368,3 +368,37 @@ def elevation_ppi(grid, grid_limits, elevation_deg, interpolation="linear", eart
     out[tz < z_min] = np.nan
     out[tz > z_max] = np.nan
     return out
+
+
+# --------------------------------------------------------------------------------------------------
+# closest-gate gridding (PyART map_gates_to_grid 'nearest'; NOT in /root/reference: parity unpinned)
+# --------------------------------------------------------------------------------------------------
+def closest_gate_grid(gate_x, gate_y, gate_z, values, excluded, grid_shape, grid_limits, roi):
+    """Value of the closest non-excluded gate within a constant ROI (ties: lowest gate index); NaN where none.
+    Restated from PyART's documented behaviour for the call at src/radar_processor/processor.py:152-163."""
+    nz, ny, nx = grid_shape
+    zc = axis_coords_f32(grid_limits[0][0], grid_limits[0][1], nz).astype(np.float64)
+    yc = axis_coords_f32(grid_limits[1][0], grid_limits[1][1], ny).astype(np.float64)
+    xc = axis_coords_f32(grid_limits[2][0], grid_limits[2][1], nx).astype(np.float64)
+    keep = ~np.asarray(excluded, dtype=bool)
+    gx = np.asarray(gate_x, dtype=np.float64)[keep]
+    gy = np.asarray(gate_y, dtype=np.float64)[keep]
+    gz = np.asarray(gate_z, dtype=np.float64)[keep]
+    val = np.asarray(values, dtype=np.float32)[keep]
+    out = np.full(grid_shape, np.nan, dtype=np.float32)
+    second = np.full(grid_shape, np.inf)          # gap to the runner-up, for tie-aware comparisons
+    for iz in range(nz):
+        for iy in range(ny):
+            d2 = (gx[None, :] - xc[:, None]) ** 2 + (gy[None, :] - yc[iy]) ** 2 + (gz[None, :] - zc[iz]) ** 2
+            d2 = np.where(d2 < roi * roi, d2, np.inf)
+            if d2.shape[1] == 0:
+                continue
+            best = np.argmin(d2, axis=1)
+            bd = d2[np.arange(nx), best]
+            ok = np.isfinite(bd)
+            out[iz, iy, ok] = val[best[ok]]
+            if d2.shape[1] > 1:
+                part = np.partition(d2, 1, axis=1)
+                with np.errstate(invalid="ignore"):          # inf - inf where fewer than two gates are in reach
+                    second[iz, iy] = np.where(np.isfinite(part[:, 1]), part[:, 1] - part[:, 0], np.inf)
+    return out, second

@@ -22,6 +22,7 @@ from .grid_products import (EARTH_RADIUS, EFFECTIVE_RADIUS_FACTOR, column_argmax
                             get_elevation_from_z_level)
 from .gridding import apply_geometry, apply_geometry_multi, grid_fields_device
 from .roi_grid import roi_grid_fields_device
+from .processor_seam import build_grid3d_package
 from .radar_adaptors import (get_available_fields, get_field_data, get_gate_coordinates, get_radar_altitude,
                              get_radar_info)
 
@@ -38,6 +39,6 @@ __all__ = [
     "get_elevation_from_z_level", "get_beam_height_difference", "compute_beam_height", "compute_beam_height_flat",
     "EARTH_RADIUS", "EFFECTIVE_RADIUS_FACTOR",
     # build-specific additions
-    "column_argmax", "grid_fields_device", "roi_grid_fields_device", "device_gate_mask", "RoiSearch", "DeviceCSR",
+    "column_argmax", "grid_fields_device", "roi_grid_fields_device", "build_grid3d_package", "device_gate_mask", "RoiSearch", "DeviceCSR",
     "NativeUnavailable", "NativeError", "load_library",
 ]

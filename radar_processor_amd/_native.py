@@ -20,7 +20,7 @@ RG_EXCLUDED_BITS = 0x7FD1CE5D
 RG_OK, RG_EINVAL, RG_EALIGN, RG_ELAUNCH, RG_EWORKSPACE, RG_EUNSUPPORTED, RG_ENODEVICE = 0, -1, -2, -3, -4, -5, -6
 GATE_OPS = {"below": 0, "above": 1, "between": 2, "outside": 3, "equal": 4, "invalid": 5}
 COLUMN_OPS = {"max": 0, "min": 1, "mean": 2}
-WEIGHTINGS = {"barnes2": 0, "cressman": 1, "nearest": 2}
+WEIGHTINGS = {"barnes2": 0, "cressman": 1, "nearest": 2, "closest": 3}
 
 
 class NativeUnavailable(RuntimeError):

@@ -125,9 +125,13 @@ __global__ __launch_bounds__(rg::kBlock) void roi_grid_kernel(SearchArgs a, cons
     const int cy0 = __builtin_amdgcn_readfirstlane(cell_clamped((double)ylo - rmax, a.c.y0, a.c.inv_cy, a.c.ncy));
     const int cy1 = __builtin_amdgcn_readfirstlane(cell_clamped((double)yhi + rmax, a.c.y0, a.c.inv_cy, a.c.ncy));
 
+    // weighted modes: acc_p = sum w*v, acc_w = sum w.  Closest-gate mode: acc_p = value of the closest gate so far,
+    // acc_w = its float32 d2 (+inf = none), best_idx = its gate index (ties go to the lower index).
+    constexpr bool CLOSEST = W == RG_W_CLOSEST;
     float acc_p[NF], acc_w[NF];
+    int best_idx[NF];
 #pragma unroll
-    for (int f = 0; f < NF; ++f) { acc_p[f] = 0.0f; acc_w[f] = 0.0f; }
+    for (int f = 0; f < NF; ++f) { acc_p[f] = 0.0f; acc_w[f] = CLOSEST ? __builtin_inff() : 0.0f; best_idx[f] = 0x7FFFFFFF; }
     int head = 0, tail = 0;  // ring positions (wave-uniform, monotone)
 
     auto dense = [&](int n) {  // test n queued records against the block's 16 voxels, 4 records per step
@@ -149,8 +153,15 @@ __global__ __launch_bounds__(rg::kBlock) void roi_grid_kernel(SearchArgs a, cons
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
               const bool ok = rg::f32_bits(val[f]) != RG_EXCLUDED_BITS;
-              acc_p[f] += ok ? w * val[f] : 0.0f;  // float32 product, as interpolate.py:82
-              acc_w[f] += ok ? w : 0.0f;
+              if constexpr (CLOSEST) {
+                const bool better = ok && (d2f < acc_w[f] || (d2f == acc_w[f] && g.index < best_idx[f]));
+                acc_p[f] = better ? val[f] : acc_p[f];
+                acc_w[f] = better ? d2f : acc_w[f];
+                best_idx[f] = better ? g.index : best_idx[f];
+              } else {
+                acc_p[f] += ok ? w * val[f] : 0.0f;  // float32 product, as interpolate.py:82
+                acc_w[f] += ok ? w : 0.0f;
+              }
             }
           }
         }
@@ -220,11 +231,23 @@ __global__ __launch_bounds__(rg::kBlock) void roi_grid_kernel(SearchArgs a, cons
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
       float p = acc_p[f], w = acc_w[f];
+      if constexpr (CLOSEST) {
+        int bi = best_idx[f];
 #pragma unroll
-      for (int m = kVB; m < 64; m <<= 1) { p += __shfl_xor(p, m, 64); w += __shfl_xor(w, m, 64); }
+        for (int m = kVB; m < 64; m <<= 1) {
+          const float op = __shfl_xor(p, m, 64), ow = __shfl_xor(w, m, 64);
+          const int oi = __shfl_xor(bi, m, 64);
+          const bool take = ow < w || (ow == w && oi < bi);
+          p = take ? op : p; w = take ? ow : w; bi = take ? oi : bi;
+        }
+      } else {
+#pragma unroll
+        for (int m = kVB; m < 64; m <<= 1) { p += __shfl_xor(p, m, 64); w += __shfl_xor(w, m, 64); }
+      }
       if (slot == 0 && vlive) {
         const size_t v = ((size_t)iz * a.ny + (iy0 + byl)) * a.nx + (ix0 + b0 + bxl);
-        out[(size_t)f * a.n_vox + v] = w > 0.0f ? (float)((double)p / (double)w) : fill;
+        if constexpr (CLOSEST) out[(size_t)f * a.n_vox + v] = w < __builtin_inff() ? p : fill;
+        else out[(size_t)f * a.n_vox + v] = w > 0.0f ? (float)((double)p / (double)w) : fill;
       }
     }
   }
@@ -269,7 +292,7 @@ extern "C" int rg_roi_grid_f32(const rg_gate4* sorted_gates, const int32_t* cell
   const int rc = check_search_args("rg_roi_grid_f32", sorted_gates, cell_start, cells_host, xc, yc, zc, nz, ny, nx);
   if (rc != RG_OK) return rc;
   RG_REQUIRE(packed && out, RG_EINVAL, "rg_roi_grid_f32: null pointer");
-  RG_REQUIRE(weighting >= RG_W_BARNES2 && weighting <= RG_W_NEAREST, RG_EINVAL, "rg_roi_grid_f32: unknown weighting %d",
+  RG_REQUIRE(weighting >= RG_W_BARNES2 && weighting <= RG_W_CLOSEST, RG_EINVAL, "rg_roi_grid_f32: unknown weighting %d",
              weighting);
   RG_REQUIRE(n_fields >= 1 && n_fields <= RG_MAX_FIELDS, RG_EUNSUPPORTED, "rg_roi_grid_f32: n_fields=%d not in 1..%d",
              n_fields, RG_MAX_FIELDS);
@@ -283,6 +306,7 @@ extern "C" int rg_roi_grid_f32(const rg_gate4* sorted_gates, const int32_t* cell
   switch (weighting) {
     case RG_W_BARNES2: return dispatch<RG_W_BARNES2>(n_fields, a, packed, fill_value, out, s);
     case RG_W_CRESSMAN: return dispatch<RG_W_CRESSMAN>(n_fields, a, packed, fill_value, out, s);
+    case RG_W_CLOSEST: return dispatch<RG_W_CLOSEST>(n_fields, a, packed, fill_value, out, s);
     default: return dispatch<RG_W_NEAREST>(n_fields, a, packed, fill_value, out, s);
   }
 }

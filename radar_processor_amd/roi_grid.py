@@ -24,7 +24,7 @@ def roi_grid_fields_device(search: RoiSearch, fields: Sequence, masks: Optional[
     :class:`RoiSearch` (cell-sorted gates) in place of the CSR geometry.  Returns ``[F, nz, ny, nx]`` float32."""
     torch = _native.torch_mod()
     lib = _native.load_library()
-    if weighting not in WEIGHTINGS:
+    if weighting not in WEIGHTINGS and weighting != "closest":   # 'closest' = single nearest gate (fused path only)
         raise ValueError(f"Unknown weighting function: {weighting}")
     n_fields = len(fields)
     if n_fields == 0:

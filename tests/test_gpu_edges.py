@@ -129,3 +129,39 @@ def test_unmasked_nan_reaches_only_its_neighbours_in_the_fused_gridder(rg):
     np.testing.assert_array_equal(np.isnan(fused), np.isnan(want))
     assert 0 < np.isnan(fused).sum() < fused.size // 2
     np.testing.assert_allclose(fused, want, rtol=1e-5, atol=6e-4, equal_nan=True)
+
+
+def test_closest_gate_mode_and_processor_seam_package(rg):
+    """rg_roi_grid_f32 in closest-gate mode + the GRID3D cache package of radar_processor/processor.py:170-179.
+    PyART is absent: checked against this build's own brute-force statement of the rule (parity unpinned)."""
+    from types import SimpleNamespace
+    from radar_processor_amd import processor_seam as seam
+    rng = np.random.default_rng(12)
+    nrays, ngates = 60, 80
+    n = nrays * ngates
+    gx = rng.uniform(-9e3, 9e3, n).astype(np.float32)
+    gy = rng.uniform(-9e3, 9e3, n).astype(np.float32)
+    gz = rng.uniform(0, 3e3, n).astype(np.float32)
+    data = rng.normal(15, 12, (nrays, ngates)).astype(np.float32)
+    data[rng.random((nrays, ngates)) < 0.1] = np.nan
+    radar = SimpleNamespace(nrays=nrays, ngates=ngates,
+                            fields={"DBZH": {"data": np.ma.masked_invalid(data), "units": "dBZ", "long_name": "refl"}},
+                            gate_x={"data": gx.reshape(nrays, ngates)}, gate_y={"data": gy.reshape(nrays, ngates)},
+                            gate_z={"data": gz.reshape(nrays, ngates)},
+                            latitude={"data": np.array([-31.4])}, longitude={"data": np.array([-64.2])})
+    excluded = rng.random(n) < 0.2
+    zl, yl, xl, res = (0.0, 2400.0), (-8000.0, 8000.0), (-6000.0, 6000.0), 400.0
+    pkg = seam.build_grid3d_package(radar, "DBZH", zl, yl, xl, res, gate_excluded=excluded)
+    shape = seam.grid3d_shape(zl, yl, xl, res)
+    assert shape == (7, 40, 30) and pkg["arr3d"].shape == shape and isinstance(pkg["arr3d"], np.ma.MaskedArray)
+    assert seam.constant_roi_for(res, yl) == max(600.0, 800 + 0.08 * 400)
+    assert pkg["x"].shape == (30,) and pkg["y"].shape == (40,) and pkg["z"].shape == (7,)
+    assert pkg["field_name"] == "DBZH" and pkg["field_metadata"] == {"units": "dBZ", "long_name": "refl"}
+    assert pkg["projection"]["proj"] == "pyart_aeqd"
+    drop = excluded | ~np.isfinite(data.ravel())
+    want, gap = oracle.closest_gate_grid(gx, gy, gz, data.ravel(), drop, shape, (zl, yl, xl), seam.constant_roi_for(res, yl))
+    got = np.ma.filled(pkg["arr3d"], np.nan)
+    clear = gap > 1e-2                      # skip voxels whose two closest gates are closer than float32 can order
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+    np.testing.assert_array_equal(got[clear], want[clear])
+    assert clear.mean() > 0.99 and np.isfinite(want).mean() > 0.5
