@@ -40,6 +40,23 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
 __device__ __forceinline__ uint32_t f32_bits(float v) { return __builtin_bit_cast(uint32_t, v); }
 __device__ __forceinline__ float bits_f32(uint32_t v) { return __builtin_bit_cast(float, v); }
 
+// One gather of a gate's packed field slots (layout of rg_pack_fields_f32: float32 [G][STRIDE], STRIDE in {1,2,4,8}).
+template <int STRIDE>
+__device__ __forceinline__ void load_packed(const float* __restrict__ p, unsigned g, float (&v)[STRIDE]) {
+  if constexpr (STRIDE == 1) {
+    v[0] = p[g];
+  } else if constexpr (STRIDE == 2) {
+    const float2 t = reinterpret_cast<const float2*>(p)[g];
+    v[0] = t.x; v[1] = t.y;
+  } else {
+#pragma unroll
+    for (int s = 0; s < STRIDE; s += 4) {
+      const float4 t = reinterpret_cast<const float4*>(p)[(size_t)g * (STRIDE / 4) + s / 4];
+      v[s] = t.x; v[s + 1] = t.y; v[s + 2] = t.z; v[s + 3] = t.w;
+    }
+  }
+}
+
 }  // namespace rg
 
 #define RG_REQUIRE(cond, code, ...)  \

@@ -30,21 +30,7 @@
 
 namespace {
 
-template <int STRIDE>
-__device__ __forceinline__ void load_packed(const float* __restrict__ p, unsigned g, float (&v)[STRIDE]) {
-  if constexpr (STRIDE == 1) {
-    v[0] = p[g];
-  } else if constexpr (STRIDE == 2) {
-    const float2 t = reinterpret_cast<const float2*>(p)[g];
-    v[0] = t.x; v[1] = t.y;
-  } else {
-#pragma unroll
-    for (int s = 0; s < STRIDE; s += 4) {
-      const float4 t = reinterpret_cast<const float4*>(p)[(size_t)g * (STRIDE / 4) + s / 4];
-      v[s] = t.x; v[s + 1] = t.y; v[s + 2] = t.z; v[s + 3] = t.w;
-    }
-  }
-}
+using rg::load_packed;
 
 // XCD placement of the 64-row chunks (speed only, never correctness):
 //   kXcdNone   workgroup b -> logical block b: neighbouring blocks land on different XCDs (round-robin deal),
