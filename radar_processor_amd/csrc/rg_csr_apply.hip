@@ -62,6 +62,8 @@ constexpr int kNoRows = 2;       // timing-only ablation: skip the row phase
 constexpr int kNonTemporal = 4;  // stream the CSR with the nt cache policy
 constexpr int kAcc32 = 8;        // per-row accumulators in float32 instead of float64 (fewer VGPRs)
 constexpr int kFlatOrder = 16;   // gather at the top of the iteration (no gather-ahead pipelining)
+constexpr int kWpb1 = 256, kWpb2 = 512, kWpb8 = 768;  // dyn kernel only: waves per workgroup (default 4)
+constexpr int wpb_of(int flags) { return (flags & 768) == 256 ? 1 : (flags & 768) == 512 ? 2 : (flags & 768) == 768 ? 8 : 4; }
 
 using f32x2 = float __attribute__((ext_vector_type(2)));
 
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(rg::kBlock) void csr_apply_kernel(
 // utilisation no longer depends on how many rows a tile happens to hold, and neither registers nor code grow
 // with the field count.  Stream / gather / product phases are identical to csr_apply_kernel.
 template <typename IndT, int NF, int STRIDE, int TILE, int XCD, int FLAGS>
-__global__ __launch_bounds__(rg::kBlock) void csr_apply_dyn_kernel(
+__global__ __launch_bounds__(64 * wpb_of(FLAGS)) void csr_apply_dyn_kernel(
     const IndT* __restrict__ indptr, const int32_t* __restrict__ gidx, const float* __restrict__ wts,
     long n_vox, long n_pairs, const float* __restrict__ packed, unsigned last_gate, float fill,
     float* __restrict__ out) {
@@ -247,15 +249,16 @@ __global__ __launch_bounds__(rg::kBlock) void csr_apply_dyn_kernel(
   constexpr int IT = TILE / 64;
   constexpr bool NT = (FLAGS & kNonTemporal) != 0;
   constexpr int kLgStride = STRIDE == 1 ? 0 : STRIDE == 2 ? 1 : STRIDE == 4 ? 2 : 3;
-  __shared__ f32x2 tile_all[rg::kBlock / rg::kWave][TILE * STRIDE];
-  __shared__ f32x2 rowacc_all[rg::kBlock / rg::kWave][64 * STRIDE];
+  constexpr int WPB = wpb_of(FLAGS);
+  __shared__ f32x2 tile_all[WPB][TILE * STRIDE];
+  __shared__ f32x2 rowacc_all[WPB][64 * STRIDE];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   f32x2* tile = tile_all[wv];
   f32x2* rowacc = rowacc_all[wv];
 
   const unsigned blk = place_block<XCD>(blockIdx.x, gridDim.x);
-  const long r0 = ((long)blk * (rg::kBlock / rg::kWave) + wv) * 64;
+  const long r0 = ((long)blk * WPB + wv) * 64;
   if (r0 >= n_vox) return;  // wave-uniform
   const long row = r0 + lane;
   const long seg_b = (long)indptr[r0];
@@ -368,9 +371,10 @@ __global__ __launch_bounds__(rg::kBlock) void csr_apply_dyn_kernel(
 template <typename IndT, int NF, int STRIDE, int TILE, int XCD, int FLAGS>
 int launch_dyn(const void* indptr, const int32_t* gidx, const float* wts, long n_vox, long n_pairs, const float* packed,
                long n_gates, float fill, float* out, hipStream_t s) {
+  constexpr int WPB = wpb_of(FLAGS);
   const long chunks = (n_vox + 63) / 64;
-  const long blocks = (chunks + 3) / 4;
-  hipLaunchKernelGGL((csr_apply_dyn_kernel<IndT, NF, STRIDE, TILE, XCD, FLAGS>), dim3((unsigned)blocks), dim3(rg::kBlock),
+  const long blocks = (chunks + WPB - 1) / WPB;
+  hipLaunchKernelGGL((csr_apply_dyn_kernel<IndT, NF, STRIDE, TILE, XCD, FLAGS>), dim3((unsigned)blocks), dim3(64 * WPB),
                      0, s, static_cast<const IndT*>(indptr), gidx, wts, n_vox, n_pairs, packed, (unsigned)(n_gates - 1),
                      fill, out);
   return rg::check_launch("rg_csr_apply_f32");
@@ -407,6 +411,9 @@ int dispatch(int nf, int variant, const void* indptr, const int32_t* gidx, const
       case 9: return RG_KD(1, 1, 384, kXcdNone, 0);
       case 10: return RG_KD(1, 1, 1024, kXcdNone, 0);
       case 15: return RG_KD(1, 1, 512, kXcdNone, kNonTemporal);
+      case 19: return RG_KD(1, 1, 512, kXcdNone, kWpb1);
+      case 20: return RG_KD(1, 1, 512, kXcdNone, kWpb2);
+      case 21: return RG_KD(1, 1, 512, kXcdNone, kWpb8);
       case 16: return RG_KD(1, 1, 512, kXcdGroup, 0);
       case 17: return RG_KD(1, 1, 640, kXcdNone, 0);
       case 18: return RG_KD(1, 1, 256, kXcdNone, 0);

@@ -165,3 +165,48 @@ def test_closest_gate_mode_and_processor_seam_package(rg):
     np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
     np.testing.assert_array_equal(got[clear], want[clear])
     assert clear.mean() > 0.99 and np.isfinite(want).mean() > 0.5
+
+
+def test_argument_validation_on_the_device_layer(rg):
+    """Bad CSRs and bad tensors are rejected by host code before anything is launched."""
+    import torch
+    dev = torch.device("cuda", 0)
+    lim = ((0, 1), (0, 1), (0, 1))
+    field = np.ma.masked_invalid(np.arange(4, dtype=np.float32))
+    bad = [
+        (np.array([0, 2, 1, 4, 4], dtype=np.int32), np.arange(4, dtype=np.int32), "non-decreasing"),       # not monotone
+        (np.array([1, 2, 3, 4, 4], dtype=np.int32), np.arange(4, dtype=np.int32), "start at 0"),            # indptr[0] != 0
+        (np.array([0, 1, 2, 3], dtype=np.int32), np.arange(4, dtype=np.int32), "entries"),                  # wrong length
+        (np.array([0, 1, 2, 3, 4], dtype=np.int32), np.array([0, -1, 2, 3], dtype=np.int32), "negative"),   # negative index
+    ]
+    for indptr, idx, msg in bad:
+        g = rg.GridGeometry((1, 2, 2), lim, indptr, idx, np.ones(4, dtype=np.float32), toa=1.0)
+        with pytest.raises(ValueError, match=msg):
+            rg.apply_geometry(g, field)
+    g = rg.GridGeometry((1, 2, 2), lim, np.arange(5, dtype=np.int32), np.arange(4, dtype=np.int32), np.ones(3, dtype=np.float32), toa=1.0)
+    with pytest.raises(ValueError, match="differ in length"):
+        rg.apply_geometry(g, field)
+    good = rg.GridGeometry((1, 2, 2), lim, np.arange(5, dtype=np.int32), np.arange(4, dtype=np.int32), np.ones(4, dtype=np.float32), toa=1.0)
+    f32 = torch.arange(4, dtype=torch.float32, device=dev)
+    with pytest.raises(ValueError, match="contiguous cuda float32"):
+        rg.grid_fields_device(good, [f32.double()])
+    with pytest.raises(ValueError, match="contiguous cuda float32"):
+        rg.grid_fields_device(good, [torch.arange(8, dtype=torch.float32, device=dev)[::2]])
+    with pytest.raises(ValueError, match="uint8"):
+        rg.grid_fields_device(good, [f32], [torch.zeros(4, dtype=torch.bool, device=dev)])
+    with pytest.raises(ValueError, match="one entry"):
+        rg.grid_fields_device(good, [f32], [None, None])
+    with pytest.raises(ValueError, match="no fields"):
+        rg.grid_fields_device(good, [])
+    with pytest.raises(rg.NativeUnavailable):
+        rg.grid_fields_device(good, [f32.cpu()])
+    out = rg.grid_fields_device(good, [f32])
+    assert out.shape == (1, 1, 2, 2) and torch.equal(out.view(-1), f32)
+    with pytest.raises(ValueError, match="unknown gate predicate"):
+        rg.device_gate_mask(f32, "sideways")
+    with pytest.raises(ValueError, match="device grids must be float32"):
+        rg.column_max(torch.zeros((2, 2, 2), dtype=torch.float64, device=dev))
+    with pytest.raises(ValueError, match="Unknown weighting function"):
+        rg.roi_grid_fields_device(rg.RoiSearch(np.zeros(1, np.float32), np.zeros(1, np.float32), np.zeros(1, np.float32),
+                                               (1, 1, 1), ((0, 0), (0, 0), (0, 0))), [torch.zeros(1, device=dev)],
+                                  weighting="gaussian")
