@@ -12,10 +12,9 @@
 // has to test are a provable superset of its ROI ball: cell_coord() is monotone in the coordinate, so a
 // gate with x - r <= gx <= x + r lies in a cell between cell(x - r) and cell(x + r).
 //
-// Work mapping: one wavefront per voxel (kVoxPerWave consecutive voxels per wave, looped).  Everything
-// per-voxel is wave-uniform (scalar loads, SALU loop control); the 64 lanes test 64 candidate gates per
-// step with one coalesced dwordx4 load each; hits are compacted with ballot + mbcnt, so a row comes out
-// in (cell row, gate index) order -- deterministic, no atomics.
+// This file holds the binning (bucket + stable radix sort + cell table) and the prefix sum of the row lengths; the
+// count / fill passes over the voxels run on the voxel-blocked search kernel of rg_roi_grid.hip, shared with the
+// fused gridder.  A row comes out in (cell row, sorted position) order -- deterministic, no atomics.
 #include <string.h>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -75,58 +74,6 @@ __global__ __launch_bounds__(rg::kBlock) void gather_sorted_kernel(const unsigne
   r.z = __fsub_rn(gz[g], radar_alt);
   r.index = (int)g;
   sorted[j] = r;
-}
-
-constexpr int kCount = 0, kFill = 1;
-
-template <int MODE, int W>
-__global__ __launch_bounds__(rg::kBlock) void roi_kernel(SearchArgs a, int* __restrict__ counts,
-                                                         const long long* __restrict__ indptr, int* __restrict__ gidx,
-                                                         float* __restrict__ wts) {
-  const int lane = threadIdx.x & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const long wave = (long)blockIdx.x * (rg::kBlock / rg::kWave) + wv;
-  const long vbeg = wave * kVoxPerWave;
-  for (int t = 0; t < kVoxPerWave; ++t) {
-    const long v = vbeg + t;
-    if (v >= a.n_vox) break;  // wave-uniform
-    const VoxelBox b = voxel_box(a, v);
-    const double x = b.x, y = b.y, z = b.z, r2 = b.r2;
-    const int cx0 = b.cx0, cx1 = b.cx1, cy0 = b.cy0, cy1 = b.cy1;
-    int count = 0;
-    long long base = 0;
-    if constexpr (MODE == kFill) base = indptr[v];
-    for (int cy = cy0; cy <= cy1; ++cy) {
-      const int s = a.cell_start[cy * a.c.ncx + cx0];
-      const int e = a.cell_start[cy * a.c.ncx + cx1 + 1];
-      for (int jb = s; jb < e; jb += 64) {
-        const int j = jb + lane;
-        bool hit = false;
-        double d2 = 0.0;
-        int gi = 0;
-        if (j < e) {
-          const rg_gate4 g = a.sorted[j];
-          const double dx = (double)g.x - x, dy = (double)g.y - y, dz = (double)g.z - z;  // compute.py:69-71
-          d2 = dx * dx + dy * dy + dz * dz;                                               // compute.py:72
-          hit = d2 < r2;                                                                  // compute.py:74
-          gi = g.index;
-        }
-        const unsigned long long m = __ballot(hit);
-        if constexpr (MODE == kFill) {
-          if (hit) {
-            const int pos = count + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
-                                                                    __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-            gidx[base + pos] = gi;
-            wts[base + pos] = roi_weight<W>(d2, r2);
-          }
-        }
-        count += __popcll(m);
-      }
-    }
-    if constexpr (MODE == kCount) {
-      if (lane == 0) counts[v] = count;
-    }
-  }
 }
 
 struct WidenI32 {
@@ -198,18 +145,6 @@ extern "C" int rg_geom_bin_gates_f32(const float* gate_x, const float* gate_y, c
   return rg::check_launch("rg_geom_bin_gates_f32");
 }
 
-extern "C" int rg_geom_count_f32(const rg_gate4* sorted_gates, const int32_t* cell_start, const rg_cellgrid* cells_host,
-                                 const float* xc, const float* yc, const float* zc, int32_t nz, int32_t ny, int32_t nx,
-                                 double min_radius, double beam_factor, int32_t* counts, rg_stream_t stream) {
-  const int rc = check_search_args("rg_geom_count_f32", sorted_gates, cell_start, cells_host, xc, yc, zc, nz, ny, nx);
-  if (rc != RG_OK) return rc;
-  RG_REQUIRE(counts, RG_EINVAL, "rg_geom_count_f32: null counts");
-  const SearchArgs a = make_args(sorted_gates, cell_start, cells_host, xc, yc, zc, nz, ny, nx, min_radius, beam_factor);
-  hipLaunchKernelGGL((roi_kernel<kCount, RG_W_NEAREST>), search_grid(a.n_vox), dim3(rg::kBlock), 0, (hipStream_t)stream, a,
-                     counts, (const long long*)nullptr, (int*)nullptr, (float*)nullptr);
-  return rg::check_launch("rg_geom_count_f32");
-}
-
 extern "C" int64_t rg_scan_workspace_bytes(int64_t n) {
   if (n < 0) return RG_EINVAL;
   size_t bytes = 0;
@@ -232,31 +167,4 @@ extern "C" int rg_scan_counts_i64(const int32_t* counts, int64_t n, int64_t* ind
                                          rocprim::plus<long long>(), (hipStream_t)stream, false);
   RG_REQUIRE(e == hipSuccess, RG_ELAUNCH, "rg_scan_counts_i64: %s", hipGetErrorString(e));
   return RG_OK;
-}
-
-extern "C" int rg_geom_fill_f32(const rg_gate4* sorted_gates, const int32_t* cell_start, const rg_cellgrid* cells_host,
-                                const float* xc, const float* yc, const float* zc, int32_t nz, int32_t ny, int32_t nx,
-                                double min_radius, double beam_factor, int32_t weighting, const int64_t* indptr,
-                                int32_t* gate_idx, float* weights, rg_stream_t stream) {
-  const int rc = check_search_args("rg_geom_fill_f32", sorted_gates, cell_start, cells_host, xc, yc, zc, nz, ny, nx);
-  if (rc != RG_OK) return rc;
-  RG_REQUIRE(indptr && gate_idx && weights, RG_EINVAL, "rg_geom_fill_f32: null pointer");
-  RG_REQUIRE(weighting >= RG_W_BARNES2 && weighting <= RG_W_NEAREST, RG_EINVAL, "rg_geom_fill_f32: unknown weighting %d",
-             weighting);
-  const SearchArgs a = make_args(sorted_gates, cell_start, cells_host, xc, yc, zc, nz, ny, nx, min_radius, beam_factor);
-  const dim3 grid = search_grid(a.n_vox), block(rg::kBlock);
-  hipStream_t s = (hipStream_t)stream;
-  const long long* ip = reinterpret_cast<const long long*>(indptr);
-  switch (weighting) {
-    case RG_W_BARNES2:
-      hipLaunchKernelGGL((roi_kernel<kFill, RG_W_BARNES2>), grid, block, 0, s, a, (int*)nullptr, ip, gate_idx, weights);
-      break;
-    case RG_W_CRESSMAN:
-      hipLaunchKernelGGL((roi_kernel<kFill, RG_W_CRESSMAN>), grid, block, 0, s, a, (int*)nullptr, ip, gate_idx, weights);
-      break;
-    default:
-      hipLaunchKernelGGL((roi_kernel<kFill, RG_W_NEAREST>), grid, block, 0, s, a, (int*)nullptr, ip, gate_idx, weights);
-      break;
-  }
-  return rg::check_launch("rg_geom_fill_f32");
 }

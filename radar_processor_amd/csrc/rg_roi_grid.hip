@@ -55,14 +55,25 @@ __device__ __forceinline__ float weight_from_f32(float d2f, float r2f, float inv
   }
 }
 
+// What the dense stage does with a (record, voxel) hit:
+//   kGridMode   accumulate the masked weighted mean (rg_roi_grid_f32)
+//   kCountMode  count it                            (rg_geom_count_f32: row lengths of the CSR)
+//   kFillMode   append (gate index, float64-exact weight) to the voxel's CSR row (rg_geom_fill_f32)
+// Count and fill classify hits with the same code, so the second pass writes exactly what the first one counted; a
+// voxel's hits arrive in (cell row, sorted position) order, the row order the CSR has always had.
+constexpr int kGridMode = 0, kCountMode = 1, kFillMode = 2;
+
 // BX x BY = 16 voxels per block (BY rows of BX consecutive voxels); a wavefront walks 4 blocks side by side in x.
-template <int W, int NF, int STRIDE, int BX>
-__global__ __launch_bounds__(rg::kBlock) void roi_grid_kernel(SearchArgs a, const float* __restrict__ packed, float fill,
-                                                              float* __restrict__ out) {
+template <int MODE, int W, int NF, int STRIDE, int BX>
+__global__ __launch_bounds__(rg::kBlock) void roi_block_kernel(SearchArgs a, const float* __restrict__ packed, float fill,
+                                                               float* __restrict__ out, int* __restrict__ counts,
+                                                               const long long* __restrict__ indptr,
+                                                               int* __restrict__ gidx, float* __restrict__ wts) {
   constexpr int kVB = 16;             // voxels per block
   constexpr int BY = kVB / BX;
   constexpr int PX = 4 * BX;          // patch of one wavefront: PX x BY voxels of one level
   constexpr int kSlots = 64 / kVB;    // queued records tested per dense step
+  static_assert(kSlots == 4, "the builder's slot masks assume 4 records per dense step");
   constexpr int kLgBX = BX == 16 ? 4 : BX == 8 ? 3 : 2;
   __shared__ rg_gate4 ring_all[rg::kBlock / rg::kWave][kRing];
   const int lane = threadIdx.x & 63;
@@ -96,7 +107,7 @@ __global__ __launch_bounds__(rg::kBlock) void roi_grid_kernel(SearchArgs a, cons
     const float xf = (float)x, yf = (float)y, r2f = (float)r2;
     // float32 d2 carries < 4e-7 relative error: outside [r2_lo, r2_hi] the float32 comparison is already exact
     const float r2_hi = vlive ? (float)(r2 * (1.0 + 2e-6)) * (1.0f + 2.4e-7f) : -1.0f;
-    const float r2_lo = (float)(r2 * (1.0 - 2e-6)) * (1.0f - 2.4e-7f);
+    const float r2_lo = vlive ? (float)(r2 * (1.0 - 2e-6)) * (1.0f - 2.4e-7f) : -1.0f;  // dead lanes never hit
     const float inv_r2q = (float)(4.0 / r2);
     // ---- block-wide (wave-uniform) quantities ------------------------------------------------------------
     double rmax = vlive ? r : 0.0;
@@ -119,19 +130,45 @@ __global__ __launch_bounds__(rg::kBlock) void roi_grid_kernel(SearchArgs a, cons
 #pragma unroll
     for (int f = 0; f < NF; ++f) { acc_p[f] = 0.0f; acc_w[f] = CLOSEST ? __builtin_inff() : 0.0f; best_idx[f] = 0x7FFFFFFF; }
     int head = 0, tail = 0;  // ring positions (wave-uniform, monotone)
+    // builder modes: hits of this lane's voxel so far (identical in the voxel's 4 slot lanes) and its row base
+    int cursor = 0;
+    long long row_base = 0;
+    if constexpr (MODE == kFillMode) {
+      if (vlive) row_base = indptr[((size_t)iz * a.ny + (iy0 + byl)) * a.nx + (ix0 + b0 + bxl)];
+    }
+    const unsigned long long vox_lanes = 0x0001000100010001ull << vl;            // the 4 slot lanes of voxel vl
+    const unsigned long long lower_slots = vox_lanes & ((1ull << (16 * slot)) - 1ull);
 
     auto dense = [&](int n) {  // test n queued records against the block's 16 voxels, 4 records per step
       for (int e0 = 0; e0 < n; e0 += kSlots) {
         const int e = e0 + slot;
+        bool in = false;
+        rg_gate4 g;
+        g.x = g.y = g.z = 0.0f; g.index = 0;
+        float d2f = 0.0f;
         if (e < n) {
-          const rg_gate4 g = ring[(head + e) & (kRing - 1)];
+          g = ring[(head + e) & (kRing - 1)];
           const float dx = g.x - xf, dy = g.y - yf, dz = g.z - zf;
-          const float d2f = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-          bool in = d2f <= r2_lo;
+          d2f = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+          in = d2f <= r2_lo;
           if (!in && d2f <= r2_hi) {  // within 2e-6 of the rim: the reference's float64 arithmetic decides
             const double ex = (double)g.x - x, ey = (double)g.y - y, ez = (double)g.z - z;  // compute.py:69-71
             in = ex * ex + ey * ey + ez * ez < r2;                                          // compute.py:72,74
           }
+        }
+        if constexpr (MODE != kGridMode) {
+          const unsigned long long hits = __ballot(in);   // executed by every lane of the wave
+          if constexpr (MODE == kFillMode) {
+            if (in) {
+              const double ex = (double)g.x - x, ey = (double)g.y - y, ez = (double)g.z - z;
+              const double d2 = ex * ex + ey * ey + ez * ez;                                // compute.py:72
+              const long long pos = row_base + cursor + __popcll(hits & lower_slots);
+              gidx[pos] = g.index;
+              wts[pos] = roi_weight<W>(d2, r2);                                             // compute.py:82-87
+            }
+          }
+          cursor += __popcll(hits & vox_lanes);
+        } else {
           if (in) {
             const float w = weight_from_f32<W>(d2f, r2f, inv_r2q);
             float val[STRIDE];
@@ -213,6 +250,12 @@ __global__ __launch_bounds__(rg::kBlock) void roi_grid_kernel(SearchArgs a, cons
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+    if constexpr (MODE == kCountMode) {
+      if (slot == 0 && vlive) counts[((size_t)iz * a.ny + (iy0 + byl)) * a.nx + (ix0 + b0 + bxl)] = cursor;
+      continue;
+    } else if constexpr (MODE == kFillMode) {
+      continue;
+    }
     // ---- fold the 4 record slots; lanes 0..15 hold the block's 16 voxels ----------------------------------
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
@@ -249,7 +292,8 @@ inline dim3 k2_grid(const SearchArgs& a) {
 template <int W, int NF, int STRIDE>
 int launch(const SearchArgs& a, const float* packed, float fill, float* out, hipStream_t s) {
   // block shape 8 x 2: measured 16.0 ms on the bench grid against 16.5 (4 x 4) and 19.4 (16 x 1)
-  hipLaunchKernelGGL((roi_grid_kernel<W, NF, STRIDE, 8>), k2_grid<8>(a), dim3(rg::kBlock), 0, s, a, packed, fill, out);
+  hipLaunchKernelGGL((roi_block_kernel<kGridMode, W, NF, STRIDE, 8>), k2_grid<8>(a), dim3(rg::kBlock), 0, s, a, packed, fill,
+                     out, (int*)nullptr, (const long long*)nullptr, (int*)nullptr, (float*)nullptr);
   return rg::check_launch("rg_roi_grid_f32");
 }
 
@@ -295,4 +339,46 @@ extern "C" int rg_roi_grid_f32(const rg_gate4* sorted_gates, const int32_t* cell
     case RG_W_CLOSEST: return dispatch<RG_W_CLOSEST>(n_fields, a, packed, fill_value, out, s);
     default: return dispatch<RG_W_NEAREST>(n_fields, a, packed, fill_value, out, s);
   }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// a6/a7 builder passes on the same block kernel: radar_grid/compute.py:54-91 for every voxel, and the CSR merge of
+// compute.py:232-272 replaced by count -> prefix sum (rg_scan_counts_i64, rg_geometry.hip) -> fill.
+// ---------------------------------------------------------------------------------------------------
+extern "C" int rg_geom_count_f32(const rg_gate4* sorted_gates, const int32_t* cell_start, const rg_cellgrid* cells_host,
+                                 const float* xc, const float* yc, const float* zc, int32_t nz, int32_t ny, int32_t nx,
+                                 double min_radius, double beam_factor, int32_t* counts, rg_stream_t stream) {
+  const int rc = check_search_args("rg_geom_count_f32", sorted_gates, cell_start, cells_host, xc, yc, zc, nz, ny, nx);
+  if (rc != RG_OK) return rc;
+  RG_REQUIRE(counts, RG_EINVAL, "rg_geom_count_f32: null counts");
+  const SearchArgs a = make_args(sorted_gates, cell_start, cells_host, xc, yc, zc, nz, ny, nx, min_radius, beam_factor);
+  hipLaunchKernelGGL((roi_block_kernel<kCountMode, RG_W_NEAREST, 1, 1, 8>), k2_grid<8>(a), dim3(rg::kBlock), 0,
+                     (hipStream_t)stream, a, (const float*)nullptr, 0.0f, (float*)nullptr, counts,
+                     (const long long*)nullptr, (int*)nullptr, (float*)nullptr);
+  return rg::check_launch("rg_geom_count_f32");
+}
+
+extern "C" int rg_geom_fill_f32(const rg_gate4* sorted_gates, const int32_t* cell_start, const rg_cellgrid* cells_host,
+                                const float* xc, const float* yc, const float* zc, int32_t nz, int32_t ny, int32_t nx,
+                                double min_radius, double beam_factor, int32_t weighting, const int64_t* indptr,
+                                int32_t* gate_idx, float* weights, rg_stream_t stream) {
+  const int rc = check_search_args("rg_geom_fill_f32", sorted_gates, cell_start, cells_host, xc, yc, zc, nz, ny, nx);
+  if (rc != RG_OK) return rc;
+  RG_REQUIRE(indptr && gate_idx && weights, RG_EINVAL, "rg_geom_fill_f32: null pointer");
+  RG_REQUIRE(weighting >= RG_W_BARNES2 && weighting <= RG_W_NEAREST, RG_EINVAL, "rg_geom_fill_f32: unknown weighting %d",
+             weighting);
+  const SearchArgs a = make_args(sorted_gates, cell_start, cells_host, xc, yc, zc, nz, ny, nx, min_radius, beam_factor);
+  const dim3 grid = k2_grid<8>(a), block(rg::kBlock);
+  hipStream_t s = (hipStream_t)stream;
+  const long long* ip = reinterpret_cast<const long long*>(indptr);
+#define RG_FILL(W_)                                                                                                     \
+  hipLaunchKernelGGL((roi_block_kernel<kFillMode, W_, 1, 1, 8>), grid, block, 0, s, a, (const float*)nullptr, 0.0f,     \
+                     (float*)nullptr, (int*)nullptr, ip, gate_idx, weights)
+  switch (weighting) {
+    case RG_W_BARNES2: RG_FILL(RG_W_BARNES2); break;
+    case RG_W_CRESSMAN: RG_FILL(RG_W_CRESSMAN); break;
+    default: RG_FILL(RG_W_NEAREST); break;
+  }
+#undef RG_FILL
+  return rg::check_launch("rg_geom_fill_f32");
 }

@@ -7,8 +7,6 @@
 namespace rg {
 namespace roi {
 
-constexpr int kVoxPerWave = 8;
-
 struct Cells {
   double x0, y0, inv_cx, inv_cy, z_lo, z_hi;
   int ncx, ncy;
@@ -71,34 +69,6 @@ inline SearchArgs make_args(const rg_gate4* sorted, const int32_t* cell_start, c
   a.n_vox = (long)nz * ny * nx;
   a.min_radius = min_radius; a.beam_factor = beam_factor;
   return a;
-}
-
-inline dim3 search_grid(long n_vox) {
-  const long waves = (n_vox + kVoxPerWave - 1) / kVoxPerWave;
-  return dim3((unsigned)((waves + 3) / 4));
-}
-
-// Per-voxel search box, wave-uniform (SGPRs): ROI radius and the cell rows / columns that cover the ball.
-struct VoxelBox {
-  double x, y, z, r2;
-  int cx0, cx1, cy0, cy1;
-};
-
-__device__ __forceinline__ VoxelBox voxel_box(const SearchArgs& a, long v) {
-  VoxelBox b;
-  const int ix = (int)(v % a.nx);
-  const long q = v / a.nx;
-  const int iy = (int)(q % a.ny);
-  const int iz = (int)(q / a.ny);
-  b.x = (double)a.xc[ix]; b.y = (double)a.yc[iy]; b.z = (double)a.zc[iz];
-  const double dist = sqrt(b.x * b.x + b.y * b.y + b.z * b.z);     // compute.py:46
-  const double r = fmax(a.min_radius, dist * a.beam_factor);       // compute.py:47
-  b.r2 = r * r;                                                    // compute.py:57
-  b.cx0 = __builtin_amdgcn_readfirstlane(cell_clamped(b.x - r, a.c.x0, a.c.inv_cx, a.c.ncx));
-  b.cx1 = __builtin_amdgcn_readfirstlane(cell_clamped(b.x + r, a.c.x0, a.c.inv_cx, a.c.ncx));
-  b.cy0 = __builtin_amdgcn_readfirstlane(cell_clamped(b.y - r, a.c.y0, a.c.inv_cy, a.c.ncy));
-  b.cy1 = __builtin_amdgcn_readfirstlane(cell_clamped(b.y + r, a.c.y0, a.c.inv_cy, a.c.ncy));
-  return b;
 }
 
 }  // namespace roi
