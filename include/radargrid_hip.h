@@ -209,6 +209,71 @@ int rg_roi_grid_f32(const rg_gate4* sorted_gates, const int32_t* cell_start, con
                     const float* packed, int32_t n_fields, int32_t stride, float fill_value, float* out,
                     rg_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * (f)3  processor-style collapse of the cached 3-D grid to the 2-D product plane:
+ * radar_processor/processor.py:480-551 (collapse_grid_to_2d) and radar_processor/utils.py:336-387
+ * (collapse_field_3d_to_2d).  'cappi' (nearest level, :530-533) and 'colmax' (:534-535) are
+ * rg_column_reduce_f32 over one level / all levels; 'ppi' (:512-528) is the entry below: per pixel
+ * r = sqrt(x^2 + y^2), z_target = r*sin_elev + r^2 / two_re (two_re = 2 * 8.49e6 m), level = first argmin of
+ * |z_target - z[k]|, all in float64 as NumPy evaluates it; out[p] = grid[level][p].  The host passes
+ * sin_elev = sin(deg2rad(elevation)).  x[nx], y[ny], z[nz] are float64 device tables.  out_level may be NULL.
+ * A masked voxel is a NaN (the cache package is masked_invalid data).
+ * ------------------------------------------------------------------------------------------------- */
+int rg_collapse_ppi_f32(const float* grid, const double* x, const double* y, const double* z, int32_t nz, int32_t ny,
+                        int32_t nx, double sin_elev, double two_re, float* out, int32_t* out_level,
+                        rg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * (f)3  threshold masks on a 2-D plane: the re-mask of collapse_grid_to_2d (processor.py:541-546:
+ * masked_less_equal / masked_less against vmin) and _apply_filter_masks (processor.py:802-886: visual filters on
+ * the plotted field, cross-field and QC filters on cached QC planes), all OR-ed in one pass.  A test drops pixel p
+ * when  q < lo (RG_TEST_LO),  q <= lo (RG_TEST_LO | RG_TEST_LO_INCLUSIVE),  q > hi (RG_TEST_HI)  or q is +-inf / NaN
+ * (RG_TEST_NONFINITE, the np.ma.masked_invalid of processor.py:541), with
+ * q = plane[p] (or src[p] when plane is NULL), compared in float32 as NumPy compares a float32 array with a Python
+ * float; NaN never compares true.  A pixel counts as already masked when src_mask[p] != 0 or, without a src_mask,
+ * when src[p] is NaN.  out[p] = dropped or masked ? NaN : src[p]  (NULL to skip); out_mask[p] = dropped or masked
+ * (NULL to skip).  `tests` is a HOST
+ * array of at most RG_MAX_PLANE_TESTS entries whose plane pointers are device pointers.
+ * ------------------------------------------------------------------------------------------------- */
+#define RG_MAX_PLANE_TESTS 12
+typedef enum rg_plane_test_flags {
+  RG_TEST_LO = 1, RG_TEST_HI = 2, RG_TEST_LO_INCLUSIVE = 4, RG_TEST_NONFINITE = 8
+} rg_plane_test_flags;
+typedef struct rg_plane_test {
+  const float* plane; /* NULL: test the source plane itself */
+  float lo, hi;
+  int32_t flags;
+} rg_plane_test;
+
+int rg_plane_filter_f32(const float* src, const uint8_t* src_mask, int64_t n, const rg_plane_test* tests,
+                        int32_t n_tests, float* out, uint8_t* out_mask, rg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * (f)4  colormap -> RGBA uint8: radar_grid/geotiff.py:70-145 (apply_colormap_to_array), i.e. matplotlib's
+ * Normalize(vmin, vmax, clip=True) followed by Colormap.__call__ and (rgba * 255).astype(uint8).
+ *
+ * rg_nan_minmax: over the pixels that are not no-data (no-data = equal to `fill` when has_fill, NaN otherwise)
+ * out[0] = min and out[1] = max ignoring NaN, out[2] = how many such non-NaN pixels there are, out[3] = how many
+ * pixels are not no-data (geotiff.py:111-125: np.nanmin / np.nanmax of valid_data and len(valid_data)); +inf / -inf /
+ * 0 when there are none.  `data` is float32 or float64 (data_is_f64), `workspace` needs RG_MINMAX_WORKSPACE_BYTES,
+ * out is double[4] on the device.
+ *
+ * rg_colormap_rgba: per pixel v = minimum(maximum(x, vmin), vmax); v -= vmin; v /= (vmax - vmin); v *= n_lut;
+ * v == n_lut -> n_lut - 1; index = trunc(v), or n_lut (under) when v < 0, n_lut + 1 (over) when v >= n_lut,
+ * n_lut + 2 (bad) when NaN; rgba = lut[index]; alpha = 0 where x is no-data (NaN, or == fill when has_fill; the
+ * comparison with fill is made in the data's dtype).  The arithmetic runs in float64 for float32 and float64 data
+ * alike: Normalize stores its limits as Python floats, so np.clip promotes a float32 array to float64 before the
+ * in-place operations (matplotlib 3.10 / NumPy 2).  vmin == vmax selects entry 0 for every pixel (Normalize fills 0);
+ * vmin > vmax is RG_EINVAL.  lut: uint8 [n_lut + 3][4] on the device = (colormap table * 255) truncated,
+ * n_lut <= RG_MAX_LUT.  out: uint8 [n][4].
+ * ------------------------------------------------------------------------------------------------- */
+#define RG_MINMAX_WORKSPACE_BYTES 32768
+#define RG_MAX_LUT 4093
+int rg_nan_minmax(const void* data, int32_t data_is_f64, int64_t n, int32_t has_fill, double fill, void* workspace,
+                  double* out, rg_stream_t stream);
+int rg_colormap_rgba(const void* data, int32_t data_is_f64, int64_t n, double vmin, double vmax, int32_t has_fill,
+                     double fill, const uint8_t* lut, int32_t n_lut, uint8_t* out, rg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

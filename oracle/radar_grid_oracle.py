@@ -402,3 +402,118 @@ def closest_gate_grid(gate_x, gate_y, gate_z, values, excluded, grid_shape, grid
                 with np.errstate(invalid="ignore"):          # inf - inf where fewer than two gates are in reach
                     second[iz, iy] = np.where(np.isfinite(part[:, 1]), part[:, 1] - part[:, 0], np.inf)
     return out, second
+
+
+# --------------------------------------------------------------------------------------------------
+# 2-D raster stage behind the 3-D grid cache
+#
+# Pinning: src/radar_processor does not import here (pyart, rasterio, cachetools are absent) and
+# src/radar_grid/geotiff.py needs rasterio at import time, so no golden vectors could be generated from the
+# reference for these functions.  They are pinned by the reference's own test expectations, which are restated in
+# tests/test_oracle_golden.py: tests/test_utils.py:209-259 (colmax == data3d.max(axis=0), cappi == nearest level,
+# ppi shape / type), tests/test_processor_phases.py:265-357 (filter masks) and
+# tests/test_geotiff_generation.py:78-127 (RGBA shape / dtype / alpha).  The PPI level choice and the RGBA colour
+# values have no known answer in the reference: "parity unpinned" beyond those properties.
+# --------------------------------------------------------------------------------------------------
+PROCESSOR_EARTH_RADIUS = 8.49e6     # "4/3 Earth radius", src/radar_processor/processor.py:517
+
+REFLECTIVITY_FIELDS = ("filled_DBZH", "DBZH", "DBZV", "DBZHF", "composite_reflectivity")   # processor.py:543
+STRICT_FIELDS = ("KDP", "ZDR")                                                              # processor.py:545
+
+
+def ppi_levels(x_coords, y_coords, z_levels, elevation_deg: float) -> np.ndarray:
+    """Level index per pixel for the processor's 'ppi' collapse (src/radar_processor/utils.py:366-371 ==
+    processor.py:512-523): beam height ``r sin(e) + r^2 / (2 Re)`` over the ground range ``r``, nearest level."""
+    xs, ys = np.meshgrid(np.asarray(x_coords), np.asarray(y_coords), indexing="xy")
+    ground = np.sqrt(xs ** 2 + ys ** 2)
+    height = ground * np.sin(np.deg2rad(elevation_deg)) + (ground ** 2) / (2.0 * PROCESSOR_EARTH_RADIUS)
+    return np.abs(height[..., None] - np.asarray(z_levels)[None, None, :]).argmin(axis=2)
+
+
+def collapse_3d_to_2d(data3d, product: str, x_coords=None, y_coords=None, z_levels=None, elevation_deg=None,
+                      target_height_m=None) -> np.ma.MaskedArray:
+    """src/radar_processor/utils.py:336-387: 'ppi' picks ``data3d[level(y, x), y, x]``, 'cappi' the level nearest
+    to the target height, 'colmax' the (masked-aware) maximum over levels; float32 masked result."""
+    if data3d.ndim == 2:
+        plane = data3d
+    elif product == "ppi":
+        levels = ppi_levels(x_coords, y_coords, z_levels, elevation_deg)
+        rows = np.arange(levels.shape[0])[:, None]
+        cols = np.arange(levels.shape[1])[None, :]
+        plane = data3d[levels, rows, cols]
+    elif product == "cappi":
+        plane = data3d[int(np.abs(np.asarray(z_levels) - float(target_height_m)).argmin())]
+    elif product == "colmax":
+        plane = data3d.max(axis=0)
+    else:
+        raise ValueError("Producto inválido")
+    return np.ma.array(plane.astype(np.float32), mask=np.ma.getmaskarray(plane))
+
+
+def collapse_remask(plane, field: str, vmin: float = -30.0) -> np.ma.MaskedArray:
+    """The re-mask at the end of collapse_grid_to_2d (src/radar_processor/processor.py:541-546)."""
+    out = np.ma.masked_invalid(plane)
+    if field in REFLECTIVITY_FIELDS:
+        out = np.ma.masked_less_equal(out, vmin)
+    elif field in STRICT_FIELDS:
+        out = np.ma.masked_less(out, vmin)
+    return out
+
+
+def filter_masks(plane: np.ma.MaskedArray, visual_filters, qc_filters, field_to_use: str, qc_planes: dict):
+    """src/radar_processor/processor.py:802-886.  Filters are objects with ``field`` / ``min`` / ``max``; a visual
+    filter on the plotted field tests the plane itself (a minimum <= 0.3 on RHOHV is skipped, :849), any other
+    filter tests the cached QC plane of its field when there is one."""
+    if not visual_filters and not qc_filters:
+        return plane
+    out = np.ma.array(plane, copy=True)
+    drop = np.zeros(out.shape, dtype=bool)
+    for flt in visual_filters:
+        name = str(getattr(flt, "field", None) or "").upper()
+        if not name:
+            continue
+        lo, hi = getattr(flt, "min", None), getattr(flt, "max", None)
+        if name == str(field_to_use).upper():
+            if lo is not None and not (lo <= 0.3 and field_to_use == "RHOHV"):
+                drop |= (out < float(lo))
+            if hi is not None:
+                drop |= (out > float(hi))
+        elif qc_planes.get(name) is not None:
+            q = qc_planes[name]
+            if lo is not None:
+                drop |= (q < float(lo))
+            if hi is not None:
+                drop |= (q > float(hi))
+    out.mask = np.ma.getmaskarray(out) | drop
+    for flt in qc_filters or ():
+        q = qc_planes.get(str(getattr(flt, "field", "") or "").upper())
+        if q is None:
+            continue
+        lo, hi = getattr(flt, "min", None), getattr(flt, "max", None)
+        hit = np.zeros(out.shape, dtype=bool)
+        if lo is not None:
+            hit |= (q < float(lo))
+        if hi is not None:
+            hit |= (q > float(hi))
+        out.mask = np.ma.getmaskarray(out) | hit
+    return out
+
+
+def colormap_rgba(data: np.ndarray, cmap, vmin=None, vmax=None, fill_value=None) -> np.ndarray:
+    """src/radar_grid/geotiff.py:70-145: no-data = NaN (or ``== fill_value``), limits default to the valid pixels'
+    nanmin / nanmax (0 / 1 when there are none), matplotlib ``Normalize(clip=True)`` then the colormap, ``* 255``
+    truncated to uint8, alpha 0 on no-data.  Calls matplotlib -- the same third-party code the reference calls."""
+    import matplotlib.pyplot as plt
+    from matplotlib.colors import Normalize
+    if isinstance(cmap, str):
+        cmap = plt.get_cmap(cmap)
+    values = data.copy()
+    nodata = (values == fill_value) if fill_value is not None else np.isnan(values)
+    valid = values[~nodata]
+    if vmin is None:
+        vmin = np.nanmin(valid) if len(valid) else 0.0
+    if vmax is None:
+        vmax = np.nanmax(valid) if len(valid) else 1.0
+    rgba = (cmap(Normalize(vmin=vmin, vmax=vmax, clip=True)(values)) * 255).astype(np.uint8)
+    rgba[nodata, 3] = 0
+    return rgba

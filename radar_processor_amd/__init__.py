@@ -23,6 +23,9 @@ from .grid_products import (EARTH_RADIUS, EFFECTIVE_RADIUS_FACTOR, column_argmax
 from .gridding import apply_geometry, apply_geometry_multi, grid_fields_device
 from .roi_grid import roi_grid_fields_device
 from .processor_seam import build_grid3d_package
+from .raster import (PlaneTest, apply_colormap_to_array, apply_filter_masks, collapse_field_3d_to_2d,
+                     collapse_grid_to_2d, collapse_plane_device, colormap_lut, colormap_rgba_device,
+                     plane_filter_device)
 from .radar_adaptors import (get_available_fields, get_field_data, get_gate_coordinates, get_radar_altitude,
                              get_radar_info)
 
@@ -37,8 +40,11 @@ __all__ = [
     "GateFilter", "create_mask_from_filter",
     "constant_altitude_ppi", "constant_elevation_ppi", "column_max", "column_min", "column_mean",
     "get_elevation_from_z_level", "get_beam_height_difference", "compute_beam_height", "compute_beam_height_flat",
-    "EARTH_RADIUS", "EFFECTIVE_RADIUS_FACTOR",
+    "EARTH_RADIUS", "EFFECTIVE_RADIUS_FACTOR", "apply_colormap_to_array",
+    # 2-D raster stage of radar_processor (utils.py:336-387, processor.py:480-551, :802-886)
+    "collapse_field_3d_to_2d", "collapse_grid_to_2d", "apply_filter_masks",
     # build-specific additions
     "column_argmax", "grid_fields_device", "roi_grid_fields_device", "build_grid3d_package", "device_gate_mask", "RoiSearch", "DeviceCSR",
+    "collapse_plane_device", "plane_filter_device", "PlaneTest", "colormap_lut", "colormap_rgba_device",
     "NativeUnavailable", "NativeError", "load_library",
 ]

@@ -21,6 +21,10 @@ RG_OK, RG_EINVAL, RG_EALIGN, RG_ELAUNCH, RG_EWORKSPACE, RG_EUNSUPPORTED, RG_ENOD
 GATE_OPS = {"below": 0, "above": 1, "between": 2, "outside": 3, "equal": 4, "invalid": 5}
 COLUMN_OPS = {"max": 0, "min": 1, "mean": 2}
 WEIGHTINGS = {"barnes2": 0, "cressman": 1, "nearest": 2, "closest": 3}
+RG_MAX_PLANE_TESTS = 12
+RG_TEST_LO, RG_TEST_HI, RG_TEST_LO_INCLUSIVE, RG_TEST_NONFINITE = 1, 2, 4, 8
+RG_MINMAX_WORKSPACE_BYTES = 32768
+RG_MAX_LUT = 4093
 
 
 class NativeUnavailable(RuntimeError):
@@ -34,6 +38,10 @@ class NativeError(RuntimeError):
 class CellGrid(Structure):
     _fields_ = [("x0", c_double), ("y0", c_double), ("inv_cx", c_double), ("inv_cy", c_double),
                 ("z_lo", c_double), ("z_hi", c_double), ("ncx", c_int32), ("ncy", c_int32)]
+
+
+class PlaneTest(Structure):
+    _fields_ = [("plane", c_void_p), ("lo", c_float), ("hi", c_float), ("flags", c_int32)]
 
 
 # name -> (restype, argtypes); mirrors include/radargrid_hip.h one to one
@@ -69,6 +77,13 @@ SIGNATURES = {
     "rg_roi_grid_f32": (c_int32, [c_void_p, c_void_p, POINTER(CellGrid), c_void_p, c_void_p, c_void_p, c_int32,
                                   c_int32, c_int32, c_double, c_double, c_int32, c_void_p, c_int32, c_int32,
                                   c_float, c_void_p, c_void_p]),
+    "rg_collapse_ppi_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_double,
+                                      c_double, c_void_p, c_void_p, c_void_p]),
+    "rg_plane_filter_f32": (c_int32, [c_void_p, c_void_p, c_int64, POINTER(PlaneTest), c_int32, c_void_p, c_void_p,
+                                      c_void_p]),
+    "rg_nan_minmax": (c_int32, [c_void_p, c_int32, c_int64, c_int32, c_double, c_void_p, c_void_p, c_void_p]),
+    "rg_colormap_rgba": (c_int32, [c_void_p, c_int32, c_int64, c_double, c_double, c_int32, c_double, c_void_p,
+                                   c_int32, c_void_p, c_void_p]),
 }
 
 _lock = threading.Lock()

@@ -26,6 +26,7 @@ SOURCES = [
     ("rg_products.hip", []),
     ("rg_geometry.hip", []),
     ("rg_roi_grid.hip", []),
+    ("rg_raster.hip", []),
 ]
 
 # Every translation unit is built with FP contraction OFF: the parity contract is NumPy's arithmetic, which
