@@ -63,6 +63,8 @@ constexpr int kNonTemporal = 4;  // stream the CSR with the nt cache policy
 constexpr int kAcc32 = 8;        // per-row accumulators in float32 instead of float64 (fewer VGPRs)
 constexpr int kFlatOrder = 16;   // gather at the top of the iteration (no gather-ahead pipelining)
 constexpr int kWpb1 = 256, kWpb2 = 512, kWpb8 = 768;  // dyn kernel only: waves per workgroup (default 4)
+constexpr int kLdsGather = 1024; // timing-only ablation (dyn kernel): gather from a 4 KiB LDS window instead of L1/L2
+constexpr int kHalfIdx = 2048;   // timing-only ablation (dyn kernel): stream 16-bit instead of 32-bit indices
 constexpr int wpb_of(int flags) { return (flags & 768) == 256 ? 1 : (flags & 768) == 512 ? 2 : (flags & 768) == 768 ? 8 : 4; }
 
 using f32x2 = float __attribute__((ext_vector_type(2)));
@@ -256,6 +258,11 @@ __global__ __launch_bounds__(64 * wpb_of(FLAGS)) void csr_apply_dyn_kernel(
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   f32x2* tile = tile_all[wv];
   f32x2* rowacc = rowacc_all[wv];
+  __shared__ float win_all[(FLAGS & kLdsGather) ? WPB : 1][(FLAGS & kLdsGather) ? 1024 : 1];
+  float* win = win_all[(FLAGS & kLdsGather) ? wv : 0];
+  if constexpr ((FLAGS & kLdsGather) != 0) {
+    for (int i = lane; i < 1024; i += 64) win[i] = packed[i];
+  }
 
   const unsigned blk = place_block<XCD>(blockIdx.x, gridDim.x);
   const long r0 = ((long)blk * WPB + wv) * 64;
@@ -283,7 +290,8 @@ __global__ __launch_bounds__(64 * wpb_of(FLAGS)) void csr_apply_dyn_kernel(
 #pragma unroll
       for (int it = 0; it < IT; ++it) {
         const int k = min(t + it * 64 + lane, kmax);
-        ci[it] = stream_load<NT>(gi + k);
+        if constexpr ((FLAGS & kHalfIdx) != 0) ci[it] = reinterpret_cast<const uint16_t*>(gi)[k];
+        else ci[it] = stream_load<NT>(gi + k);
         cw[it] = stream_load<NT>(wi + k);
       }
     };
@@ -291,7 +299,8 @@ __global__ __launch_bounds__(64 * wpb_of(FLAGS)) void csr_apply_dyn_kernel(
 #pragma unroll
       for (int it = 0; it < IT; ++it) {
         w_n[it] = cw[it];
-        load_packed<STRIDE>(packed, min((unsigned)ci[it], last_gate), val_n[it]);  // clamp: never fault
+        if constexpr ((FLAGS & kLdsGather) != 0) val_n[it][0] = win[ci[it] & 1023];
+        else load_packed<STRIDE>(packed, min((unsigned)ci[it], last_gate), val_n[it]);  // clamp: never fault
       }
     };
 
@@ -415,6 +424,9 @@ int dispatch(int nf, int variant, const void* indptr, const int32_t* gidx, const
       case 20: return RG_KD(1, 1, 512, kXcdNone, kWpb2);
       case 21: return RG_KD(1, 1, 512, kXcdNone, kWpb8);
       case 16: return RG_KD(1, 1, 512, kXcdGroup, 0);
+      case 22: return RG_KD(1, 1, 512, kXcdNone, kLdsGather);             // timing-only ablations of the dyn kernel
+      case 23: return RG_KD(1, 1, 512, kXcdNone, kLdsGather | kHalfIdx);
+      case 24: return RG_KD(1, 1, 512, kXcdNone, kHalfIdx);
       case 17: return RG_KD(1, 1, 640, kXcdNone, 0);
       case 18: return RG_KD(1, 1, 256, kXcdNone, 0);
       case 11: return RG_K1(1, 1, 512, kXcdNone, kNoGather);   // timing-only ablations
