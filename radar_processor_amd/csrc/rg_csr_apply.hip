@@ -63,8 +63,7 @@ constexpr int kNonTemporal = 4;  // stream the CSR with the nt cache policy
 constexpr int kAcc32 = 8;        // per-row accumulators in float32 instead of float64 (fewer VGPRs)
 constexpr int kFlatOrder = 16;   // gather at the top of the iteration (no gather-ahead pipelining)
 constexpr int kWpb1 = 256, kWpb2 = 512, kWpb8 = 768;  // dyn kernel only: waves per workgroup (default 4)
-constexpr int kLdsGather = 1024; // timing-only ablation (dyn kernel): gather from a 4 KiB LDS window instead of L1/L2
-constexpr int kHalfIdx = 2048;   // timing-only ablation (dyn kernel): stream 16-bit instead of 32-bit indices
+constexpr int kStages3 = 1024;   // dyn kernel only: three CSR tiles in flight per wavefront instead of two
 constexpr int wpb_of(int flags) { return (flags & 768) == 256 ? 1 : (flags & 768) == 512 ? 2 : (flags & 768) == 768 ? 8 : 4; }
 
 using f32x2 = float __attribute__((ext_vector_type(2)));
@@ -236,12 +235,48 @@ __global__ __launch_bounds__(rg::kBlock) void csr_apply_kernel(
   }
 }
 
-// Variant of the kernel above with a DYNAMIC row phase, used for fused multi-field passes: per tile the rows that
-// actually touch it (a contiguous range, found with one ballot) share the 64 lanes -- L = the largest power of
-// two <= 64 / rows (at least `stride`) lanes per row, split into stride field slots x L/stride interleaved
-// element streams -- and the per-row sums live in a small LDS array instead of per-pass registers.  Lane
-// utilisation no longer depends on how many rows a tile happens to hold, and neither registers nor code grow
-// with the field count.  Stream / gather / product phases are identical to csr_apply_kernel.
+// DEFAULT kernel: same stream / gather / product phases as csr_apply_kernel, with
+//   * a DYNAMIC row phase: per tile the rows that actually touch it (a contiguous range, found with one ballot) share
+//     the 64 lanes -- L = the largest power of two <= 64 / rows (at least `stride`) lanes per row, split into stride
+//     field slots x L/stride interleaved element streams -- and the per-row sums live in a small LDS array instead of
+//     per-pass registers, so lane utilisation does not depend on how many rows a tile holds and neither registers nor
+//     code grow with the field count;
+//   * BUFFER loads: the CSR tile and the packed fields are read through buffer resources, whose hardware range check
+//     returns 0 for anything past the end of the array.  That removes every address clamp and all 64-bit address
+//     arithmetic from the loop: a tile's resource is rebuilt in SGPRs (base + t, remaining bytes), the lane offset
+//     is the constant 4 * lane and the 8 loads of a tile differ only in the instruction's immediate offset;
+//   * a software pipeline unrolled by two (see the comment inside).
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+constexpr int kRsrcRaw32 = 0x00020000;   // gfx9 buffer resource word 3: DATA_FORMAT = 32, untyped dword access
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, long bytes) {   // `base` and `bytes` wave-uniform
+  const unsigned nb = bytes >= 0xFFFFFFFFL ? 0xFFFFFFFFu : bytes <= 0 ? 0u : (unsigned)bytes;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)nb, kRsrcRaw32);
+}
+
+// 8- and 16-byte buffer loads by intrinsic name: this compiler's __builtin_amdgcn_raw_buffer_load_b64 / _b128 return
+// the first dword in every element (seen in the generated code), the intrinsics themselves are fine
+using f32x4 = float __attribute__((ext_vector_type(4)));
+__device__ f32x2 buffer_load_v2f32(rsrc_t, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.ptr.buffer.load.v2f32");
+__device__ f32x4 buffer_load_v4f32(rsrc_t, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.ptr.buffer.load.v4f32");
+
+template <int STRIDE>
+__device__ __forceinline__ void buffer_load_packed(rsrc_t r, unsigned gate, float (&v)[STRIDE]) {
+  const int off = (int)(gate * (4u * STRIDE));   // a corrupt index lands out of range -> the load returns 0
+  if constexpr (STRIDE == 1) {
+    v[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+  } else if constexpr (STRIDE == 2) {
+    const f32x2 t = buffer_load_v2f32(r, off, 0, 0);
+    v[0] = t.x; v[1] = t.y;
+  } else {
+#pragma unroll
+    for (int q = 0; q < STRIDE; q += 4) {
+      const f32x4 t = buffer_load_v4f32(r, off + 4 * q, 0, 0);
+      v[q] = t.x; v[q + 1] = t.y; v[q + 2] = t.z; v[q + 3] = t.w;
+    }
+  }
+}
+
 template <typename IndT, int NF, int STRIDE, int TILE, int XCD, int FLAGS>
 __global__ __launch_bounds__(64 * wpb_of(FLAGS)) void csr_apply_dyn_kernel(
     const IndT* __restrict__ indptr, const int32_t* __restrict__ gidx, const float* __restrict__ wts,
@@ -249,20 +284,16 @@ __global__ __launch_bounds__(64 * wpb_of(FLAGS)) void csr_apply_dyn_kernel(
     float* __restrict__ out) {
   static_assert(TILE % 64 == 0, "a wave handles 64 pairs per step");
   constexpr int IT = TILE / 64;
-  constexpr bool NT = (FLAGS & kNonTemporal) != 0;
+  static_assert(IT * 256 <= 4096, "the tile's loads are told apart by a 12-bit immediate offset");
   constexpr int kLgStride = STRIDE == 1 ? 0 : STRIDE == 2 ? 1 : STRIDE == 4 ? 2 : 3;
   constexpr int WPB = wpb_of(FLAGS);
+  constexpr int NST = (FLAGS & kStages3) ? 3 : 2;   // tiles of CSR in flight per wavefront
   __shared__ f32x2 tile_all[WPB][TILE * STRIDE];
   __shared__ f32x2 rowacc_all[WPB][64 * STRIDE];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   f32x2* tile = tile_all[wv];
   f32x2* rowacc = rowacc_all[wv];
-  __shared__ float win_all[(FLAGS & kLdsGather) ? WPB : 1][(FLAGS & kLdsGather) ? 1024 : 1];
-  float* win = win_all[(FLAGS & kLdsGather) ? wv : 0];
-  if constexpr ((FLAGS & kLdsGather) != 0) {
-    for (int i = lane; i < 1024; i += 64) win[i] = packed[i];
-  }
 
   const unsigned blk = place_block<XCD>(blockIdx.x, gridDim.x);
   const long r0 = ((long)blk * WPB + wv) * 64;
@@ -277,53 +308,57 @@ __global__ __launch_bounds__(64 * wpb_of(FLAGS)) void csr_apply_dyn_kernel(
   for (int f = 0; f < STRIDE; ++f) rowacc[lane * STRIDE + f] = (f32x2)(0.0f);
 
   if (span > 0) {
+    // Software pipeline over the tiles.  Stage k mod NST holds tile k's indices and weights, value set k mod NST
+    // its gathered field values; one step of tile k issues the gather of tile k+1 (its indices were streamed NST-1
+    // steps ago), turns tile k into products, streams tile k+NST into the stage it just freed and runs tile k's
+    // row phase while all of that is in flight.  Two rules keep the compiler's wait counts exact:
+    //  * the loop is unrolled by NST, so every load lands in the register it is consumed from -- a rotating
+    //    register set would be copied, and a copy has to wait for the load it copies;
+    //  * every step issues the same loads, unconditionally.  The buffer resources end at the chunk's last pair, so
+    //    loads past it are dropped by the range check (no memory traffic, they return 0) instead of being branched
+    //    around -- a branch would make the number of loads in flight path-dependent and force full waits.
+    struct Stage {
+      int ci[IT];
+      float cw[IT];
+    };
+    struct Values {
+      float v[IT][STRIDE];
+    };
+    Stage st[NST];
+    Values vl[NST];
     const int32_t* __restrict__ gi = gidx + seg_b;
     const float* __restrict__ wi = wts + seg_b;
-    const long tail = n_pairs - 1 - seg_b;
-    const int kmax = tail < 0x3FFFFFFF ? (int)tail : 0x3FFFFFFF;
-    int ci[IT];
-    float cw[IT];
-    float w_n[IT];
-    float val_n[IT][STRIDE];
+    const int lane4 = lane * 4;
+    const rsrc_t rp = make_rsrc(packed, ((long)last_gate + 1) * (4 * STRIDE));
 
-    auto stream = [&](int t) {
+    auto stream = [&](Stage& sg, int t) {   // t wave-uniform: the resources live in SGPRs
+      const rsrc_t ri = make_rsrc(gi + t, ((long)span - t) * 4);
+      const rsrc_t rw = make_rsrc(wi + t, ((long)span - t) * 4);
 #pragma unroll
       for (int it = 0; it < IT; ++it) {
-        const int k = min(t + it * 64 + lane, kmax);
-        if constexpr ((FLAGS & kHalfIdx) != 0) ci[it] = reinterpret_cast<const uint16_t*>(gi)[k];
-        else ci[it] = stream_load<NT>(gi + k);
-        cw[it] = stream_load<NT>(wi + k);
+        sg.ci[it] = __builtin_amdgcn_raw_buffer_load_b32(ri, lane4 + it * 256, 0, 0);
+        sg.cw[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, lane4 + it * 256, 0, 0));
       }
     };
-    auto gather = [&]() {
+    auto gather = [&](const Stage& sg, Values& val) {
 #pragma unroll
-      for (int it = 0; it < IT; ++it) {
-        w_n[it] = cw[it];
-        if constexpr ((FLAGS & kLdsGather) != 0) val_n[it][0] = win[ci[it] & 1023];
-        else load_packed<STRIDE>(packed, min((unsigned)ci[it], last_gate), val_n[it]);  // clamp: never fault
-      }
+      for (int it = 0; it < IT; ++it) buffer_load_packed<STRIDE>(rp, (unsigned)sg.ci[it], val.v[it]);
     };
-
-    stream(0);
-    gather();
-    if (TILE < span) stream(TILE);
-    for (int t = 0; t < span; t += TILE) {
+    auto step = [&](int t, Stage& cur, const Stage& nxt, const Values& val, Values& val_nxt) {
+      gather(nxt, val_nxt);
       // ---- products of tile t -> LDS ---------------------------------------------------------------
 #pragma unroll
       for (int it = 0; it < IT; ++it) {
 #pragma unroll
         for (int f = 0; f < STRIDE; ++f) {  // padding slots hold the sentinel -> (0, 0)
-          const bool ok = f < NF && rg::f32_bits(val_n[it][f]) != RG_EXCLUDED_BITS;
+          const bool ok = f < NF && rg::f32_bits(val.v[it][f]) != RG_EXCLUDED_BITS;
           f32x2 e;
-          e.x = ok ? w_n[it] * val_n[it][f] : 0.0f;
-          e.y = ok ? w_n[it] : 0.0f;
+          e.x = ok ? cur.cw[it] * val.v[it][f] : 0.0f;
+          e.y = ok ? cur.cw[it] : 0.0f;
           tile[(it * 64 + lane) * STRIDE + f] = e;
         }
       }
-      if (t + TILE < span) {  // gather for tile t+1, CSR stream for tile t+2: in flight during the row phase
-        gather();
-        if (t + 2 * TILE < span) stream(t + 2 * TILE);
-      }
+      stream(cur, t + NST * TILE);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -364,6 +399,19 @@ __global__ __launch_bounds__(64 * wpb_of(FLAGS)) void csr_apply_dyn_kernel(
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+
+    stream(st[0], 0);
+    gather(st[0], vl[0]);
+#pragma unroll
+    for (int u = 1; u < NST; ++u) stream(st[u], u * TILE);
+    for (int t = 0; t < span;) {
+#pragma unroll
+      for (int u = 0; u < NST; ++u) {
+        step(t, st[u], st[(u + 1) % NST], vl[u], vl[(u + 1) % NST]);
+        t += TILE;
+        if (t >= span) break;
+      }
     }
   }
 
@@ -418,15 +466,16 @@ int dispatch(int nf, int variant, const void* indptr, const int32_t* gidx, const
       case 7: return RG_K1(1, 1, 384, kXcdNone, 0);
       case 8: return RG_K1(1, 1, 512, kXcdSlab, 0);
       case 9: return RG_KD(1, 1, 384, kXcdNone, 0);
-      case 10: return RG_KD(1, 1, 1024, kXcdNone, 0);
-      case 15: return RG_KD(1, 1, 512, kXcdNone, kNonTemporal);
       case 19: return RG_KD(1, 1, 512, kXcdNone, kWpb1);
       case 20: return RG_KD(1, 1, 512, kXcdNone, kWpb2);
       case 21: return RG_KD(1, 1, 512, kXcdNone, kWpb8);
       case 16: return RG_KD(1, 1, 512, kXcdGroup, 0);
-      case 22: return RG_KD(1, 1, 512, kXcdNone, kLdsGather);             // timing-only ablations of the dyn kernel
-      case 23: return RG_KD(1, 1, 512, kXcdNone, kLdsGather | kHalfIdx);
-      case 24: return RG_KD(1, 1, 512, kXcdNone, kHalfIdx);
+      case 22: return RG_KD(1, 1, 512, kXcdNone, kStages3);
+      case 23: return RG_KD(1, 1, 448, kXcdNone, 0);
+      case 24: return RG_KD(1, 1, 384, kXcdNone, kStages3);
+      case 25: return RG_KD(1, 1, 256, kXcdNone, kStages3);
+      case 26: return RG_KD(1, 1, 320, kXcdNone, kStages3);
+      case 27: return RG_KD(1, 1, 384, kXcdNone, kStages3 | kWpb2);
       case 17: return RG_KD(1, 1, 640, kXcdNone, 0);
       case 18: return RG_KD(1, 1, 256, kXcdNone, 0);
       case 11: return RG_K1(1, 1, 512, kXcdNone, kNoGather);   // timing-only ablations
@@ -466,6 +515,9 @@ extern "C" int rg_csr_apply_f32_ex(const void* indptr, int32_t indptr_is_i64, co
   RG_REQUIRE(n_pairs == 0 || (gate_idx && weights && packed && n_gates > 0), RG_EINVAL,
              "rg_csr_apply_f32: pairs present but gate_idx/weights/packed/n_gates missing");
   RG_REQUIRE(n_gates <= 0x7FFFFFFFL, RG_EUNSUPPORTED, "rg_csr_apply_f32: n_gates exceeds int32 gate indices");
+  RG_REQUIRE(n_gates * stride * 4 <= 0xFFFFFFFFL, RG_EUNSUPPORTED,
+             "rg_csr_apply_f32: the packed fields (%ld gates x %d slots) exceed the 4 GiB one buffer resource addresses",
+             (long)n_gates, stride);
   RG_REQUIRE(n_vox <= 0x3FFFFFFFFFL, RG_EUNSUPPORTED, "rg_csr_apply_f32: n_vox too large for one launch");
   RG_REQUIRE(rg::aligned16(packed), RG_EALIGN, "rg_csr_apply_f32: packed must be 16-byte aligned");
   if (n_vox == 0) return RG_OK;
