@@ -183,7 +183,7 @@ def main():
         geom = rg.GridGeometry(shape, limits, None, None, None, toa=17000.0)
         n_pairs = None
         algo_bytes = (12 + 5 * n_ff) * n_gates + 4 * n_ff * n_vox
-        kernel_name = "roi_grid_kernel"
+        kernel_name = "roi_block_kernel"
     torch.cuda.synchronize()
     t_geom = time.perf_counter() - t0
     log(f"rank {rank}: geometry ({args.mode}) ready in {t_geom:.1f}s"

@@ -97,7 +97,8 @@ int rg_pack_fields_f32(int32_t n_fields, const float* const* fields_host, const 
  *   out[f*n_vox + v] = sum_j w_j*val_f(g_j) / sum_j w_j   over pairs j of row v whose gate is not EXCLUDED
  *                      for field f, if that weight sum is > 0; otherwise fill_value.
  * Products are float32 (as in the reference), sums are accumulated in float64 and rounded once.
- * gate indices are clamped to [0, n_gates) before the gather (a corrupt index cannot fault the GPU).
+ * the gather goes through a range-checked buffer resource of n_gates * stride * 4 bytes (which must stay below
+ * 4 GiB): a gate index outside [0, n_gates) reads as 0.0 and cannot fault the GPU.
  * indptr must be non-decreasing with indptr[0] = 0 and indptr[n_vox] = n_pairs.
  * ------------------------------------------------------------------------------------------------- */
 int rg_csr_apply_f32(const void* indptr, int32_t indptr_is_i64, const int32_t* gate_idx, const float* weights,

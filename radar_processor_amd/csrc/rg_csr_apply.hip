@@ -342,7 +342,14 @@ __global__ __launch_bounds__(64 * wpb_of(FLAGS)) void csr_apply_dyn_kernel(
     };
     auto gather = [&](const Stage& sg, Values& val) {
 #pragma unroll
-      for (int it = 0; it < IT; ++it) buffer_load_packed<STRIDE>(rp, (unsigned)sg.ci[it], val.v[it]);
+      for (int it = 0; it < IT; ++it) {
+        if constexpr ((FLAGS & kNoGather) != 0) {   // timing-only ablation
+#pragma unroll
+          for (int f = 0; f < STRIDE; ++f) val.v[it][f] = __builtin_bit_cast(float, sg.ci[it]);
+        } else {
+          buffer_load_packed<STRIDE>(rp, (unsigned)sg.ci[it], val.v[it]);
+        }
+      }
     };
     auto step = [&](int t, Stage& cur, const Stage& nxt, const Values& val, Values& val_nxt) {
       gather(nxt, val_nxt);
@@ -470,6 +477,7 @@ int dispatch(int nf, int variant, const void* indptr, const int32_t* gidx, const
       case 20: return RG_KD(1, 1, 512, kXcdNone, kWpb2);
       case 21: return RG_KD(1, 1, 512, kXcdNone, kWpb8);
       case 16: return RG_KD(1, 1, 512, kXcdGroup, 0);
+      case 28: return RG_KD(1, 1, 512, kXcdNone, kNoGather);            // timing-only ablation of the default kernel
       case 22: return RG_KD(1, 1, 512, kXcdNone, kStages3);
       case 23: return RG_KD(1, 1, 448, kXcdNone, 0);
       case 24: return RG_KD(1, 1, 384, kXcdNone, kStages3);
