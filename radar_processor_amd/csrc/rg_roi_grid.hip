@@ -31,7 +31,9 @@ namespace {
 
 using namespace rg::roi;
 
-constexpr int kRing = 128;  // queue slots per wave (power of two, >= 2 * 64)
+// queue slots per wave (power of two).  Builder modes: <= 63 waiting + 64 new records.  Grid mode: + the 64 records
+// of the previous step whose field values are still in flight.
+constexpr int kRingBuild = 128, kRingGrid = 256;
 
 using rg::load_packed;
 
@@ -75,10 +77,16 @@ __global__ __launch_bounds__(rg::kBlock) void roi_block_kernel(SearchArgs a, con
   constexpr int kSlots = 64 / kVB;    // queued records tested per dense step
   static_assert(kSlots == 4, "the builder's slot masks assume 4 records per dense step");
   constexpr int kLgBX = BX == 16 ? 4 : BX == 8 ? 3 : 2;
+  constexpr bool GRID = MODE == kGridMode;
+  constexpr int kRing = GRID ? kRingGrid : kRingBuild;
   __shared__ rg_gate4 ring_all[rg::kBlock / rg::kWave][kRing];
+  // grid mode: the packed field slots of every queued gate, fetched ONCE when the gate is queued (a queued gate hits
+  // up to 16 voxels over several dense steps; gathering per hit also put a memory round trip into every dense step)
+  __shared__ float ringv_all[rg::kBlock / rg::kWave][GRID ? kRing * STRIDE : 1];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   rg_gate4* ring = ring_all[wv];
+  float* ringv = ringv_all[wv];
   const long wpx = (a.nx + PX - 1) / PX, wpy = (a.ny + BY - 1) / BY;   // patches per level
   const long wave = (long)blockIdx.x * (rg::kBlock / rg::kWave) + wv;
   const long iz_l = wave / (wpx * wpy);
@@ -130,6 +138,7 @@ __global__ __launch_bounds__(rg::kBlock) void roi_block_kernel(SearchArgs a, con
 #pragma unroll
     for (int f = 0; f < NF; ++f) { acc_p[f] = 0.0f; acc_w[f] = CLOSEST ? __builtin_inff() : 0.0f; best_idx[f] = 0x7FFFFFFF; }
     int head = 0, tail = 0;  // ring positions (wave-uniform, monotone)
+    int ready = 0;           // records [head, ready) are complete (grid mode: their values have been parked)
     // builder modes: hits of this lane's voxel so far (identical in the voxel's 4 slot lanes) and its row base
     int cursor = 0;
     long long row_base = 0;
@@ -140,21 +149,27 @@ __global__ __launch_bounds__(rg::kBlock) void roi_block_kernel(SearchArgs a, con
     const unsigned long long lower_slots = vox_lanes & ((1ull << (16 * slot)) - 1ull);
 
     auto dense = [&](int n) {  // test n queued records against the block's 16 voxels, 4 records per step
+      // the next step's record (and, in grid mode, its field slots) is read from LDS before this step's arithmetic,
+      // so the LDS latency overlaps it; slots past n hold stale but addressable ring entries and are ignored
+      rg_gate4 g_nx = ring[(head + slot) & (kRing - 1)];
+      float val_nx[STRIDE];
+      if constexpr (GRID) load_packed<STRIDE>(ringv, (unsigned)((head + slot) & (kRing - 1)), val_nx);
       for (int e0 = 0; e0 < n; e0 += kSlots) {
         const int e = e0 + slot;
-        bool in = false;
-        rg_gate4 g;
-        g.x = g.y = g.z = 0.0f; g.index = 0;
-        float d2f = 0.0f;
-        if (e < n) {
-          g = ring[(head + e) & (kRing - 1)];
-          const float dx = g.x - xf, dy = g.y - yf, dz = g.z - zf;
-          d2f = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-          in = d2f <= r2_lo;
-          if (!in && d2f <= r2_hi) {  // within 2e-6 of the rim: the reference's float64 arithmetic decides
-            const double ex = (double)g.x - x, ey = (double)g.y - y, ez = (double)g.z - z;  // compute.py:69-71
-            in = ex * ex + ey * ey + ez * ez < r2;                                          // compute.py:72,74
-          }
+        const rg_gate4 g = g_nx;
+        float val[STRIDE];
+#pragma unroll
+        for (int f = 0; f < STRIDE; ++f) val[f] = GRID ? val_nx[f] : 0.0f;
+        if (e0 + kSlots < n) {
+          g_nx = ring[(head + e + kSlots) & (kRing - 1)];
+          if constexpr (GRID) load_packed<STRIDE>(ringv, (unsigned)((head + e + kSlots) & (kRing - 1)), val_nx);
+        }
+        const float dx = g.x - xf, dy = g.y - yf, dz = g.z - zf;
+        const float d2f = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+        bool in = e < n && d2f <= r2_lo;
+        if (e < n && !in && d2f <= r2_hi) {  // within 2e-6 of the rim: the reference's float64 arithmetic decides
+          const double ex = (double)g.x - x, ey = (double)g.y - y, ez = (double)g.z - z;  // compute.py:69-71
+          in = ex * ex + ey * ey + ez * ez < r2;                                          // compute.py:72,74
         }
         if constexpr (MODE != kGridMode) {
           const unsigned long long hits = __ballot(in);   // executed by every lane of the wave
@@ -171,8 +186,6 @@ __global__ __launch_bounds__(rg::kBlock) void roi_block_kernel(SearchArgs a, con
         } else {
           if (in) {
             const float w = weight_from_f32<W>(d2f, r2f, inv_r2q);
-            float val[STRIDE];
-            load_packed<STRIDE>(packed, (unsigned)g.index, val);
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
               const bool ok = rg::f32_bits(val[f]) != RG_EXCLUDED_BITS;
@@ -190,6 +203,21 @@ __global__ __launch_bounds__(rg::kBlock) void roi_block_kernel(SearchArgs a, con
         }
       }
       head += n;
+    };
+
+    // grid mode: the survivor this lane queued in the previous candidate step and its values, still in flight
+    bool pend = false;
+    int pend_pos = 0;
+    float pend_val[STRIDE];
+#pragma unroll
+    for (int f = 0; f < STRIDE; ++f) pend_val[f] = 0.0f;
+    auto flush_pending = [&]() {
+      if (pend) {
+#pragma unroll
+        for (int f = 0; f < STRIDE; ++f) ringv[pend_pos * STRIDE + f] = pend_val[f];
+      }
+      pend = false;
+      ready = tail;
     };
 
     const int nrows = cy1 - cy0 + 1;
@@ -222,6 +250,7 @@ __global__ __launch_bounds__(rg::kBlock) void roi_block_kernel(SearchArgs a, con
         const bool valid = vn;
         have = advance();
         if (have) { vn = jb + lane < je; if (vn) gn = a.sorted[jb + lane]; }  // prefetch the next step
+        if constexpr (GRID) flush_pending();   // the values requested one step ago have had that step to arrive
         // lower bound of the distance to the nearest voxel of the block vs the block's largest (inflated) radius
         const float dz = g.z - zf;
         const float dxb = fmaxf(fmaxf(xlo - g.x, g.x - xhi), 0.0f);
@@ -232,9 +261,15 @@ __global__ __launch_bounds__(rg::kBlock) void roi_block_kernel(SearchArgs a, con
         if (pre) {
           const int pos = tail + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
           ring[pos & (kRing - 1)] = g;
+          if constexpr (GRID) {   // request the gate's field slots now, park them in the ring one step later
+            pend = true;
+            pend_pos = pos & (kRing - 1);
+            load_packed<STRIDE>(packed, (unsigned)g.index, pend_val);
+          }
         }
         tail += __popcll(m);
-        if (tail - head >= 64) {
+        if constexpr (!GRID) ready = tail;
+        if (ready - head >= 64) {   // only records whose values are in the ring (builder modes: ready == tail)
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -242,6 +277,7 @@ __global__ __launch_bounds__(rg::kBlock) void roi_block_kernel(SearchArgs a, con
         }
       }
     }
+    if constexpr (GRID) flush_pending();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
