@@ -28,6 +28,16 @@
 
 #include "rg_common.hpp"
 
+// 8- and 16-byte buffer loads by intrinsic name: this compiler's __builtin_amdgcn_raw_buffer_load_b64 / _b128 return
+// the first dword in every element (seen in the generated code), the intrinsics themselves are fine.  Declared at
+// namespace scope: a name bound to an intrinsic must not have internal linkage.
+using rg_f32x2 = float __attribute__((ext_vector_type(2)));
+using rg_f32x4 = float __attribute__((ext_vector_type(4)));
+__device__ rg_f32x2 rg_buffer_load_v2f32(__amdgpu_buffer_rsrc_t, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.raw.ptr.buffer.load.v2f32");
+__device__ rg_f32x4 rg_buffer_load_v4f32(__amdgpu_buffer_rsrc_t, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.raw.ptr.buffer.load.v4f32");
+
 namespace {
 
 using rg::load_packed;
@@ -254,11 +264,6 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* base, long bytes) {   //
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)nb, kRsrcRaw32);
 }
 
-// 8- and 16-byte buffer loads by intrinsic name: this compiler's __builtin_amdgcn_raw_buffer_load_b64 / _b128 return
-// the first dword in every element (seen in the generated code), the intrinsics themselves are fine
-using f32x4 = float __attribute__((ext_vector_type(4)));
-__device__ f32x2 buffer_load_v2f32(rsrc_t, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.ptr.buffer.load.v2f32");
-__device__ f32x4 buffer_load_v4f32(rsrc_t, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.ptr.buffer.load.v4f32");
 
 template <int STRIDE>
 __device__ __forceinline__ void buffer_load_packed(rsrc_t r, unsigned gate, float (&v)[STRIDE]) {
@@ -266,12 +271,12 @@ __device__ __forceinline__ void buffer_load_packed(rsrc_t r, unsigned gate, floa
   if constexpr (STRIDE == 1) {
     v[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
   } else if constexpr (STRIDE == 2) {
-    const f32x2 t = buffer_load_v2f32(r, off, 0, 0);
+    const rg_f32x2 t = rg_buffer_load_v2f32(r, off, 0, 0);
     v[0] = t.x; v[1] = t.y;
   } else {
 #pragma unroll
     for (int q = 0; q < STRIDE; q += 4) {
-      const f32x4 t = buffer_load_v4f32(r, off + 4 * q, 0, 0);
+      const rg_f32x4 t = rg_buffer_load_v4f32(r, off + 4 * q, 0, 0);
       v[q] = t.x; v[q + 1] = t.y; v[q + 2] = t.z; v[q + 3] = t.w;
     }
   }
