@@ -4,7 +4,7 @@
 // volume on a 40x2000x2000 grid is ~24 G pairs = 195 GB, 11x over the reference's int32 indptr).
 //
 // Bound: NOT HBM (compulsory traffic is only the sorted gates + packed fields + the output grid); the kernel is
-// limited by VALU issue for the candidate test and by the L1/L2-served loads of gate records.
+// limited by VALU issue, mostly in the dense stage (about 21 VALU instructions per 64 (record, voxel) tests).
 //
 // Structure (one wavefront = a 32 x 2 patch of one grid level, processed as 4 blocks of 8 x 2 = 16 voxels):
 //   * voxel blocking: neighbouring voxels (240 m apart, ROI >= 250 m) share almost all candidates, so every gate
@@ -19,7 +19,9 @@
 //     constants live in its registers, its sums never leave it -- and tests 4 records per step (LDS broadcast
 //     reads).  float32 d2 decides membership whenever it is clear of the rim by 2e-6; inside that band the lane
 //     falls back to the reference's exact float64 `d2 < r2` (compute.py:69-74), so the neighbour set equals the
-//     CSR builder's.  Weight in float32 (|rel err| < 2e-6), one gather per (record, voxel) hit served by L1;
+//     CSR builder's.  Weight in float32 (|rel err| < 2e-6).  The packed field slots of a gate are fetched once,
+//     when the gate is queued, and parked in a second LDS ring one candidate step later; the dense stage reads
+//     records and values from LDS one step ahead of its arithmetic;
 //   * per block two wavefront shuffles fold the 4 record slots; 16 lanes store 16 consecutive voxels per field.
 //
 // Compiled with -ffp-contract=off like every TU (the exact test must not be fused); the float32 tests use explicit
