@@ -33,8 +33,8 @@ namespace {
 
 using namespace rg::roi;
 
-// queue slots per wave (power of two).  Builder modes: <= 63 waiting + 64 new records.  Grid mode: + the 64 records
-// of the previous step whose field values are still in flight.
+// queue slots per wave (power of two): <= 63 waiting + 64 new records; with the value ring + the 64 records of the
+// previous step whose field values are still in flight.
 constexpr int kRingBuild = 128, kRingGrid = 256;
 
 using rg::load_packed;
@@ -80,11 +80,14 @@ __global__ __launch_bounds__(rg::kBlock) void roi_block_kernel(SearchArgs a, con
   static_assert(kSlots == 4, "the builder's slot masks assume 4 records per dense step");
   constexpr int kLgBX = BX == 16 ? 4 : BX == 8 ? 3 : 2;
   constexpr bool GRID = MODE == kGridMode;
-  constexpr int kRing = GRID ? kRingGrid : kRingBuild;
+  // Value ring (grid mode, 1-2 field slots): the packed field slots of every queued gate are fetched ONCE, when the
+  // gate is queued (a queued gate hits up to 16 voxels over several dense steps; gathering per hit also puts a memory
+  // round trip into every dense step).  With 4 or 8 slots the ring would cost 4-8 KiB more LDS per wavefront and an
+  // unconditional 16-32 byte LDS read per lane and step -- measured 35 % slower than gathering per hit, which stays.
+  constexpr bool VRING = GRID && STRIDE <= 2;
+  constexpr int kRing = VRING ? kRingGrid : kRingBuild;
   __shared__ rg_gate4 ring_all[rg::kBlock / rg::kWave][kRing];
-  // grid mode: the packed field slots of every queued gate, fetched ONCE when the gate is queued (a queued gate hits
-  // up to 16 voxels over several dense steps; gathering per hit also put a memory round trip into every dense step)
-  __shared__ float ringv_all[rg::kBlock / rg::kWave][GRID ? kRing * STRIDE : 1];
+  __shared__ float ringv_all[rg::kBlock / rg::kWave][VRING ? kRing * STRIDE : 1];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   rg_gate4* ring = ring_all[wv];
@@ -151,27 +154,46 @@ __global__ __launch_bounds__(rg::kBlock) void roi_block_kernel(SearchArgs a, con
     const unsigned long long lower_slots = vox_lanes & ((1ull << (16 * slot)) - 1ull);
 
     auto dense = [&](int n) {  // test n queued records against the block's 16 voxels, 4 records per step
-      // the next step's record (and, in grid mode, its field slots) is read from LDS before this step's arithmetic,
+      // value-ring variant: the next step's record and field slots are read from LDS before this step's arithmetic,
       // so the LDS latency overlaps it; slots past n hold stale but addressable ring entries and are ignored
-      rg_gate4 g_nx = ring[(head + slot) & (kRing - 1)];
+      rg_gate4 g_nx;
+      g_nx.x = g_nx.y = g_nx.z = 0.0f; g_nx.index = 0;
       float val_nx[STRIDE];
-      if constexpr (GRID) load_packed<STRIDE>(ringv, (unsigned)((head + slot) & (kRing - 1)), val_nx);
+#pragma unroll
+      for (int f = 0; f < STRIDE; ++f) val_nx[f] = 0.0f;
+      if constexpr (VRING) {
+        g_nx = ring[(head + slot) & (kRing - 1)];
+        load_packed<STRIDE>(ringv, (unsigned)((head + slot) & (kRing - 1)), val_nx);
+      }
       for (int e0 = 0; e0 < n; e0 += kSlots) {
         const int e = e0 + slot;
-        const rg_gate4 g = g_nx;
+        bool in = false;
+        rg_gate4 g = g_nx;
+        float d2f = 0.0f;
         float val[STRIDE];
 #pragma unroll
-        for (int f = 0; f < STRIDE; ++f) val[f] = GRID ? val_nx[f] : 0.0f;
-        if (e0 + kSlots < n) {
-          g_nx = ring[(head + e + kSlots) & (kRing - 1)];
-          if constexpr (GRID) load_packed<STRIDE>(ringv, (unsigned)((head + e + kSlots) & (kRing - 1)), val_nx);
-        }
-        const float dx = g.x - xf, dy = g.y - yf, dz = g.z - zf;
-        const float d2f = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-        bool in = e < n && d2f <= r2_lo;
-        if (e < n && !in && d2f <= r2_hi) {  // within 2e-6 of the rim: the reference's float64 arithmetic decides
-          const double ex = (double)g.x - x, ey = (double)g.y - y, ez = (double)g.z - z;  // compute.py:69-71
-          in = ex * ex + ey * ey + ez * ez < r2;                                          // compute.py:72,74
+        for (int f = 0; f < STRIDE; ++f) val[f] = val_nx[f];
+        if constexpr (VRING) {
+          if (e0 + kSlots < n) {
+            g_nx = ring[(head + e + kSlots) & (kRing - 1)];
+            load_packed<STRIDE>(ringv, (unsigned)((head + e + kSlots) & (kRing - 1)), val_nx);
+          }
+          const float dx = g.x - xf, dy = g.y - yf, dz = g.z - zf;
+          d2f = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+          in = e < n && d2f <= r2_lo;
+          if (e < n && !in && d2f <= r2_hi) {  // within 2e-6 of the rim: the reference's float64 arithmetic decides
+            const double ex = (double)g.x - x, ey = (double)g.y - y, ez = (double)g.z - z;  // compute.py:69-71
+            in = ex * ex + ey * ey + ez * ez < r2;                                          // compute.py:72,74
+          }
+        } else if (e < n) {
+          g = ring[(head + e) & (kRing - 1)];
+          const float dx = g.x - xf, dy = g.y - yf, dz = g.z - zf;
+          d2f = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+          in = d2f <= r2_lo;
+          if (!in && d2f <= r2_hi) {  // within 2e-6 of the rim: the reference's float64 arithmetic decides
+            const double ex = (double)g.x - x, ey = (double)g.y - y, ez = (double)g.z - z;  // compute.py:69-71
+            in = ex * ex + ey * ey + ez * ez < r2;                                          // compute.py:72,74
+          }
         }
         if constexpr (MODE != kGridMode) {
           const unsigned long long hits = __ballot(in);   // executed by every lane of the wave
@@ -188,6 +210,7 @@ __global__ __launch_bounds__(rg::kBlock) void roi_block_kernel(SearchArgs a, con
         } else {
           if (in) {
             const float w = weight_from_f32<W>(d2f, r2f, inv_r2q);
+            if constexpr (!VRING) load_packed<STRIDE>(packed, (unsigned)g.index, val);   // one gather per hit
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
               const bool ok = rg::f32_bits(val[f]) != RG_EXCLUDED_BITS;
@@ -252,7 +275,7 @@ __global__ __launch_bounds__(rg::kBlock) void roi_block_kernel(SearchArgs a, con
         const bool valid = vn;
         have = advance();
         if (have) { vn = jb + lane < je; if (vn) gn = a.sorted[jb + lane]; }  // prefetch the next step
-        if constexpr (GRID) flush_pending();   // the values requested one step ago have had that step to arrive
+        if constexpr (VRING) flush_pending();   // the values requested one step ago have had that step to arrive
         // lower bound of the distance to the nearest voxel of the block vs the block's largest (inflated) radius
         const float dz = g.z - zf;
         const float dxb = fmaxf(fmaxf(xlo - g.x, g.x - xhi), 0.0f);
@@ -263,15 +286,15 @@ __global__ __launch_bounds__(rg::kBlock) void roi_block_kernel(SearchArgs a, con
         if (pre) {
           const int pos = tail + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
           ring[pos & (kRing - 1)] = g;
-          if constexpr (GRID) {   // request the gate's field slots now, park them in the ring one step later
+          if constexpr (VRING) {  // request the gate's field slots now, park them in the ring one step later
             pend = true;
             pend_pos = pos & (kRing - 1);
             load_packed<STRIDE>(packed, (unsigned)g.index, pend_val);
           }
         }
         tail += __popcll(m);
-        if constexpr (!GRID) ready = tail;
-        if (ready - head >= 64) {   // only records whose values are in the ring (builder modes: ready == tail)
+        if constexpr (!VRING) ready = tail;
+        if (ready - head >= 64) {   // only records whose values are in the ring (without a value ring: ready == tail)
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -279,7 +302,7 @@ __global__ __launch_bounds__(rg::kBlock) void roi_block_kernel(SearchArgs a, con
         }
       }
     }
-    if constexpr (GRID) flush_pending();
+    if constexpr (VRING) flush_pending();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
