@@ -18,7 +18,8 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-from radar_processor_amd import (GateFilter, apply_geometry, apply_geometry_multi, column_argmax, column_max,  # noqa: E402
+from radar_processor_amd import (GateFilter, apply_colormap_to_array, apply_filter_masks, apply_geometry,  # noqa: E402
+                                 apply_geometry_multi, collapse_field_3d_to_2d, column_argmax, column_max,
                                  compute_grid_geometry, constant_altitude_ppi, constant_elevation_ppi,
                                  get_field_data, get_gate_coordinates, get_radar_info, load_geometry, save_geometry)
 from radar_processor_amd import synthetic  # noqa: E402
@@ -64,6 +65,23 @@ def main():
     print(f"CAPPI@4000 m max {np.nanmax(cappi):.1f} dBZ | COLMAX max {np.nanmax(colmax):.1f} dBZ at level "
           f"{int(level.ravel()[np.nanargmax(colmax)])} | PPI 0.9 deg: {np.isfinite(ppi).mean():.1%} of pixels inside the grid")
     assert np.array_equal(colmax, column_max(grids["DBZH"]), equal_nan=True)
+
+    # 4. the 2-D tier of process_radar_to_cog: processor-style collapse, visual + QC filter masks, colormap -> RGBA
+    class Range:                                     # what the processor's filter objects look like
+        def __init__(self, field, lo, hi):
+            self.field, self.min, self.max = field, lo, hi
+
+    nz, ny, nx = geometry.grid_shape
+    (z_lo, z_hi), (y_lo, y_hi), (x_lo, x_hi) = geometry.grid_limits
+    axes = dict(x_coords=np.linspace(x_lo, x_hi, nx), y_coords=np.linspace(y_lo, y_hi, ny),
+                z_levels=np.linspace(z_lo, z_hi, nz))
+    planes = {n: collapse_field_3d_to_2d(np.ma.masked_invalid(grids[n]), "ppi", elevation_deg=0.9, **axes)
+              for n in ("DBZH", "RHOHV")}
+    shown = apply_filter_masks(planes["DBZH"], [Range("DBZH", -10.0, None)], [Range("RHOHV", 0.85, None)], "DBZH",
+                               {"qc": {"RHOHV": planes["RHOHV"]}})
+    rgba = apply_colormap_to_array(shown.filled(np.nan), "turbo", vmin=-10.0, vmax=70.0)
+    print(f"processor-style PPI: {shown.count()} of {shown.size} pixels shown -> RGBA {rgba.shape} {rgba.dtype}, "
+          f"{(rgba[..., 3] == 0).mean():.1%} transparent")
 
 
 if __name__ == "__main__":

@@ -275,6 +275,16 @@ int rg_nan_minmax(const void* data, int32_t data_is_f64, int64_t n, int32_t has_
 int rg_colormap_rgba(const void* data, int32_t data_is_f64, int64_t n, double vmin, double vmax, int32_t has_fill,
                      double fill, const uint8_t* lut, int32_t n_lut, uint8_t* out, rg_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * GridFilter (radar_grid/filters.py:609-780): value filters on a product plane after interpolation.
+ * out[p] = hit(p) ? fill_value : src[p]  with  hit = (flags & RG_TEST_LO and v < lo) or (flags & RG_TEST_HI and v > hi)
+ * or (flags & RG_TEST_NONFINITE and v is NaN / +-inf) or (mask != NULL and mask[p] != 0); comparisons in the
+ * plane's dtype (float32 when data_is_f64 == 0, as NumPy compares a float32 array with a Python float), so a NaN
+ * pixel is only ever replaced by the NONFINITE test or the mask.  src == out is allowed.
+ * ------------------------------------------------------------------------------------------------- */
+int rg_grid_filter(const void* src, int32_t data_is_f64, int64_t n, int32_t flags, double lo, double hi,
+                   const uint8_t* mask, double fill_value, void* out, rg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

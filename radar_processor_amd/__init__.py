@@ -13,7 +13,7 @@ without the built library and a HIP device every compute entry point raises ``Na
 ``radar-processor_amd`` at the repository root is a symlink to it.)
 """
 from ._native import NativeError, NativeUnavailable, load_library
-from .gate_filters import GateFilter, create_mask_from_filter, device_gate_mask
+from .gate_filters import GateFilter, GridFilter, create_mask_from_filter, device_gate_mask
 from .geometry_builder import RoiSearch, compute_grid_geometry
 from .grid_geometry import DeviceCSR, GridGeometry, load_geometry, save_geometry
 from .grid_products import (EARTH_RADIUS, EFFECTIVE_RADIUS_FACTOR, column_argmax, column_max, column_mean,
@@ -37,7 +37,7 @@ __all__ = [
     "compute_grid_geometry",
     "apply_geometry", "apply_geometry_multi",
     "get_gate_coordinates", "get_field_data", "get_available_fields", "get_radar_info", "get_radar_altitude",
-    "GateFilter", "create_mask_from_filter",
+    "GateFilter", "GridFilter", "create_mask_from_filter",
     "constant_altitude_ppi", "constant_elevation_ppi", "column_max", "column_min", "column_mean",
     "get_elevation_from_z_level", "get_beam_height_difference", "compute_beam_height", "compute_beam_height_flat",
     "EARTH_RADIUS", "EFFECTIVE_RADIUS_FACTOR", "apply_colormap_to_array",

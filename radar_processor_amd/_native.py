@@ -81,6 +81,8 @@ SIGNATURES = {
                                       c_double, c_void_p, c_void_p, c_void_p]),
     "rg_plane_filter_f32": (c_int32, [c_void_p, c_void_p, c_int64, POINTER(PlaneTest), c_int32, c_void_p, c_void_p,
                                       c_void_p]),
+    "rg_grid_filter": (c_int32, [c_void_p, c_int32, c_int64, c_int32, c_double, c_double, c_void_p, c_double, c_void_p,
+                                 c_void_p]),
     "rg_nan_minmax": (c_int32, [c_void_p, c_int32, c_int64, c_int32, c_double, c_void_p, c_void_p, c_void_p]),
     "rg_colormap_rgba": (c_int32, [c_void_p, c_int32, c_int64, c_double, c_double, c_int32, c_double, c_void_p,
                                    c_int32, c_void_p, c_void_p]),

@@ -63,6 +63,20 @@ __global__ __launch_bounds__(rg::kBlock) void plane_filter_kernel(const float* _
   if (out_mask) out_mask[p] = masked ? 1 : 0;
 }
 
+template <typename T>
+__global__ __launch_bounds__(rg::kBlock) void grid_filter_kernel(const T* __restrict__ src, long n, int flags, T lo, T hi,
+                                                                 const uint8_t* __restrict__ mask, T fill,
+                                                                 T* __restrict__ out) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const T v = src[p];
+  bool hit = mask && mask[p];
+  if (flags & RG_TEST_LO) hit |= v < lo;                                   // filters.py:657
+  if (flags & RG_TEST_HI) hit |= v > hi;                                   // filters.py:686
+  if (flags & RG_TEST_NONFINITE) hit |= !(fabs((double)v) < __builtin_inf());   // filters.py:746
+  out[p] = hit ? fill : v;
+}
+
 // ---- min / max / count of the valid pixels ---------------------------------------------------------------
 constexpr int kMinmaxBlocks = 1024;   // partials: 4 doubles per block -> 32 KiB of workspace
 
@@ -253,4 +267,22 @@ extern "C" int rg_colormap_rgba(const void* data, int32_t data_is_f64, int64_t n
   else
     launch_colormap<float>(data, (long)n, vmin, vmax, flat, has_fill, fill, lut, n_lut, out, s);
   return rg::check_launch("rg_colormap_rgba");
+}
+
+extern "C" int rg_grid_filter(const void* src, int32_t data_is_f64, int64_t n, int32_t flags, double lo, double hi,
+                              const uint8_t* mask, double fill_value, void* out, rg_stream_t stream) {
+  RG_REQUIRE(n >= 0, RG_EINVAL, "rg_grid_filter: negative size");
+  RG_REQUIRE((flags & ~(RG_TEST_LO | RG_TEST_HI | RG_TEST_NONFINITE)) == 0, RG_EINVAL, "rg_grid_filter: unknown flags 0x%x",
+             flags);
+  if (n == 0) return RG_OK;
+  RG_REQUIRE(src && out, RG_EINVAL, "rg_grid_filter: null pointer");
+  const unsigned blocks = (unsigned)((n + rg::kBlock - 1) / rg::kBlock);
+  hipStream_t s = (hipStream_t)stream;
+  if (data_is_f64)
+    hipLaunchKernelGGL(grid_filter_kernel<double>, dim3(blocks), dim3(rg::kBlock), 0, s, static_cast<const double*>(src),
+                       (long)n, flags, lo, hi, mask, fill_value, static_cast<double*>(out));
+  else
+    hipLaunchKernelGGL(grid_filter_kernel<float>, dim3(blocks), dim3(rg::kBlock), 0, s, static_cast<const float*>(src),
+                       (long)n, flags, (float)lo, (float)hi, mask, (float)fill_value, static_cast<float*>(out));
+  return rg::check_launch("rg_grid_filter");
 }

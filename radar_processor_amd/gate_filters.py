@@ -220,3 +220,68 @@ def device_gate_mask(data, op: str, a: float = 0.0, b: float = 0.0, mask=None):
         _native.check(lib.rg_gate_mask_f32(_native.ptr(data), data.numel(), _native.GATE_OPS[op], float(a), float(b),
                                            _native.ptr(mask), _native.stream_ptr()), "rg_gate_mask_f32")
     return mask
+
+
+# ============================================================================
+# GridFilter -- applied after interpolation on 2-D projections (radar_grid/filters.py:609-780)
+# ============================================================================
+class GridFilter:
+    """Value filters on a product plane (``radar_grid/filters.py:609-780``, same methods): pixels below / above a
+    threshold, outside a range, NaN / Inf, or flagged by a custom function are set to ``fill_value`` (NaN by
+    default); the input is never modified.  NumPy arrays (float32 or float64, any shape) are staged through HBM and
+    come back as NumPy; cuda tensors stay on the device.  The comparison runs in the array's dtype, exactly as
+    NumPy compares an array with a Python number (``rg_grid_filter``)."""
+
+    @staticmethod
+    def _run(grid, flags: int, lo: float = 0.0, hi: float = 0.0, mask=None, fill_value: float = np.nan):
+        torch = _native.torch_mod()
+        lib = _native.load_library()
+        is_tensor = type(grid).__module__.startswith("torch")
+        if is_tensor:
+            if not grid.is_cuda:
+                raise _native.NativeUnavailable("GridFilter runs on the GPU: pass a cuda tensor or a NumPy array")
+            src = grid.contiguous()
+        else:
+            arr = np.asarray(grid)
+            if arr.dtype not in (np.float32, np.float64):
+                arr = arr.astype(np.float64)        # the reference would fail to store NaN in an integer grid
+            src = torch.from_numpy(np.ascontiguousarray(arr)).to(_native.device())
+        if src.dtype not in (torch.float32, torch.float64):
+            raise ValueError("grid must be float32 or float64")
+        mask_t = None
+        if mask is not None:
+            if type(mask).__module__.startswith("torch"):
+                mask_t = mask.to(device=src.device, dtype=torch.uint8).contiguous()
+            else:
+                mask_t = torch.from_numpy(np.ascontiguousarray(np.asarray(mask, dtype=bool).astype(np.uint8))).to(src.device)
+            if mask_t.numel() != src.numel():
+                raise ValueError("the custom mask must have the shape of the grid")
+        out = torch.empty_like(src)
+        with torch.cuda.device(src.device):
+            _native.check(lib.rg_grid_filter(_native.ptr(src), int(src.dtype == torch.float64), src.numel(), flags,
+                                             float(lo), float(hi), _native.ptr(mask_t), float(fill_value),
+                                             _native.ptr(out), _native.stream_ptr()), "rg_grid_filter")
+        return out if is_tensor else out.cpu().numpy()
+
+    def apply_below(self, grid, threshold: float, fill_value: float = np.nan):
+        """Set values ``< threshold`` to ``fill_value`` (``filters.py:631-658``)."""
+        return self._run(grid, _native.RG_TEST_LO, lo=threshold, fill_value=fill_value)
+
+    def apply_above(self, grid, threshold: float, fill_value: float = np.nan):
+        """Set values ``> threshold`` to ``fill_value`` (``filters.py:660-687``)."""
+        return self._run(grid, _native.RG_TEST_HI, hi=threshold, fill_value=fill_value)
+
+    def apply_outside_range(self, grid, vmin: float, vmax: float, fill_value: float = np.nan):
+        """Set values outside ``[vmin, vmax]`` to ``fill_value`` (``filters.py:689-720``)."""
+        return self._run(grid, _native.RG_TEST_LO | _native.RG_TEST_HI, lo=vmin, hi=vmax, fill_value=fill_value)
+
+    def apply_invalid(self, grid, fill_value: float = np.nan):
+        """Set NaN and Inf values to ``fill_value`` (``filters.py:722-748``)."""
+        return self._run(grid, _native.RG_TEST_NONFINITE, fill_value=fill_value)
+
+    def apply_custom(self, grid, func: Callable, fill_value: float = np.nan):
+        """``func(grid)`` returns a boolean mask, True = set to ``fill_value`` (``filters.py:750-780``).  The
+        function itself is the caller's code and runs wherever ``grid`` lives; only the masked assignment is ours."""
+        if type(grid).__module__.startswith("torch"):
+            return self._run(grid, 0, mask=func(grid.clone()), fill_value=fill_value)
+        return self._run(grid, 0, mask=func(np.array(grid, copy=True)), fill_value=fill_value)

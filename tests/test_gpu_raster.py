@@ -286,3 +286,75 @@ def test_colormap_full_size_device_resident(rg):
     codes = set(map(tuple, lut[:, :3]))
     assert set(map(tuple, np.unique(rgba[~np.isnan(plane)][:, :3], axis=0))) <= codes
     np.testing.assert_array_equal(rgba[::8, ::8], oracle.colormap_rgba(plane[::8, ::8], "turbo", -10.0, 70.0))
+
+
+# ------------------------------------------------------------------------------------------------
+# GridFilter (radar_grid/filters.py:609-780): the reference's tests/test_grid_filters.py, through rg_grid_filter
+# ------------------------------------------------------------------------------------------------
+def _ref_grid_filter(grid, kind, *args, fill_value=np.nan):
+    """The reference's arithmetic, restated: copy, boolean mask, masked assignment (filters.py:655-779)."""
+    out = grid.copy()
+    if kind == "below":
+        out[out < args[0]] = fill_value
+    elif kind == "above":
+        out[out > args[0]] = fill_value
+    elif kind == "outside":
+        out[(out < args[0]) | (out > args[1])] = fill_value
+    elif kind == "invalid":
+        out[np.isnan(out) | np.isinf(out)] = fill_value
+    else:
+        out[args[0](out)] = fill_value
+    return out
+
+
+def test_grid_filter_reference_tests(rg):
+    gf = rg.GridFilter()
+    grid = np.array([[10.0, 20.0, 30.0, 40.0], [15.0, 25.0, 35.0, 45.0], [12.0, 22.0, 32.0, 42.0]])
+    keep = grid.copy()
+    out = gf.apply_below(grid, 15)                                   # test_grid_filters.py:29-52
+    assert np.isnan(out[0, 0]) and np.isnan(out[2, 0]) and out[0, 1] == 20.0 and out[1, 0] == 15.0
+    np.testing.assert_array_equal(grid, keep)
+    colmax = np.array([[8.0, 18.0, 28.0, 38.0, 48.0], [12.0, 22.0, 32.0, 42.0, 52.0], [10.0, 20.0, 30.0, 40.0, 50.0],
+                       [14.0, 24.0, 34.0, 44.0, 54.0]])
+    out = gf.apply_above(colmax, 40)                                 # :84-96
+    assert np.isnan(out[0, 4]) and np.isnan(out[3, 4]) and out[0, 0] == 8.0 and out[0, 3] == 38.0
+    out = gf.apply_outside_range(colmax, 15, 45)                     # :98-113
+    assert np.isnan(out[0, 0]) and np.isnan(out[1, 4]) and out[0, 1] == 18.0 and out[0, 3] == 38.0
+    out = gf.apply_invalid(np.array([[10.0, np.inf, 30.0], [15.0, -np.inf, np.nan]]))   # :119-155
+    assert np.isnan(out[0, 1]) and np.isnan(out[1, 1]) and np.isnan(out[1, 2]) and out[0, 0] == 10.0
+    out = gf.apply_custom(np.array([[5.0, 10.0, 15.0, 20.0], [25.0, 30.0, 35.0, 40.0]]),
+                          lambda x: (x.astype(int) % 2) != 0)        # :176-195
+    np.testing.assert_array_equal(np.isnan(out), [[True, False, True, False], [True, False, True, False]])
+    row = np.array([[5.0, 15.0, 25.0]])
+    np.testing.assert_array_equal(gf.apply_below(row, 15, fill_value=-9999), [[-9999, 15.0, 25.0]])   # :201-210
+    np.testing.assert_array_equal(gf.apply_above(row, 15, fill_value=-999), [[5.0, 15.0, -999]])     # :212-221
+    chained = gf.apply_above(gf.apply_below(np.array([[5.0, 15.0, 25.0, 35.0], [10.0, 20.0, 30.0, 40.0]]), 12), 35)
+    np.testing.assert_array_equal(np.isnan(chained), [[True, False, False, False], [True, False, False, True]])
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_grid_filter_bit_exact(rg, dtype):
+    import torch
+    rng = np.random.default_rng(17)
+    plane = rng.uniform(5, 50, (257, 131)).astype(dtype)
+    plane[rng.random(plane.shape) < 0.1] = np.nan
+    plane[3, 4], plane[5, 6] = np.inf, -np.inf
+    thr = 15.000001                     # not representable in float32: the comparison dtype matters
+    gf = rg.GridFilter()
+    cases = [("below", (thr,), {}), ("above", (40.3,), {}), ("outside", (thr, 40.3), {}), ("invalid", (), {}),
+             ("below", (thr,), {"fill_value": -9999.0}), ("invalid", (), {"fill_value": 0.0}),
+             ("custom", (lambda x: np.abs(x - 30) < 3,), {"fill_value": -1.0})]
+    for kind, args, kw in cases:
+        want = _ref_grid_filter(plane, kind, *args, **kw)
+        fn = {"below": gf.apply_below, "above": gf.apply_above, "outside": gf.apply_outside_range,
+              "invalid": gf.apply_invalid, "custom": gf.apply_custom}[kind]
+        got = fn(plane, *args, **kw)
+        assert got.dtype == dtype and got.shape == plane.shape
+        np.testing.assert_array_equal(got, want, err_msg=f"{kind} {kw}")
+    # device-resident input stays on the device
+    t = torch.from_numpy(plane).cuda()
+    out = gf.apply_outside_range(t, thr, 40.3)
+    assert out.is_cuda and out.dtype == t.dtype
+    np.testing.assert_array_equal(out.cpu().numpy(), _ref_grid_filter(plane, "outside", thr, 40.3))
+    out = gf.apply_custom(t, lambda x: x > 45)
+    np.testing.assert_array_equal(out.cpu().numpy(), _ref_grid_filter(plane, "custom", lambda x: x > 45))
