@@ -285,6 +285,25 @@ int rg_colormap_rgba(const void* data, int32_t data_is_f64, int64_t n, double vm
 int rg_grid_filter(const void* src, int32_t data_is_f64, int64_t n, int32_t flags, double lo, double hi,
                    const uint8_t* mask, double fill_value, void* out, rg_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * K1c  csr_apply over a compact device copy of the CSR -- same results as rg_csr_apply_f32 for one field, bit for
+ * bit, from 6 instead of 8 streamed bytes per pair and one gather per DISTINCT gate of a chunk instead of one per
+ * pair.  Rows are grouped in chunks of RG_COMPACT_ROWS consecutive voxels; chunk c lists its distinct gate indices
+ * in dict[dict_ptr[c] .. dict_ptr[c+1]) (at most 65536 of them, any order) and pair p of one of its rows stores
+ * local_idx[p] = position of its gate in that list.  indptr and weights are those of the standard CSR
+ * (radar_grid/geometry.py:46-52), which stays the interchange format; the compact arrays are derived from it on the
+ * device (radar_processor_amd/grid_geometry.py: CompactCSR).  `packed` is the stride-1 layout of rg_pack_fields_f32.
+ * window_cap: how many dictionary values a workgroup keeps in LDS (<= RG_COMPACT_MAX_WINDOW); chunks with a longer
+ * dictionary gather per pair from memory, so any value is correct and the choice only affects speed.
+ * tile: pairs per pipeline step, 0 = default.
+ * ------------------------------------------------------------------------------------------------- */
+#define RG_COMPACT_ROWS 256
+#define RG_COMPACT_MAX_WINDOW 8192
+int rg_csr_compact_apply_f32(const void* indptr, int32_t indptr_is_i64, const uint16_t* local_idx, const float* weights,
+                             const int64_t* dict_ptr, const int32_t* dict, int64_t n_vox, int64_t n_pairs,
+                             const float* packed, int64_t n_gates, float fill_value, float* out, int32_t window_cap,
+                             int32_t tile, rg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

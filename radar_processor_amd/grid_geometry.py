@@ -40,6 +40,71 @@ class DeviceCSR:
         return sum(int(t.numel()) * t.element_size() for t in (self.indptr, self.gate_indices, self.weights))
 
 
+class CompactCSR:
+    """Compact device copy of a :class:`DeviceCSR` for ``rg_csr_compact_apply_f32``: rows grouped in chunks of
+    ``RG_COMPACT_ROWS``, each chunk's distinct gates listed once (``dict`` / ``dict_ptr``) and a 16-bit position in
+    that list per pair (``local_idx``).  ``indptr`` and ``weights`` are shared with the standard CSR."""
+
+    __slots__ = ("local_idx", "dict_ptr", "dict", "n_dict", "max_dict", "window_cap")
+
+    def __init__(self, local_idx, dict_ptr, dict_, max_dict: int, window_cap: int):
+        self.local_idx = local_idx          # int16 storage of the uint16 positions [P]
+        self.dict_ptr = dict_ptr            # int64 [chunks + 1]
+        self.dict = dict_                   # int32 [D]
+        self.n_dict = int(dict_.shape[0])
+        self.max_dict = int(max_dict)
+        self.window_cap = int(window_cap)   # LDS window the kernel is launched with (speed only)
+
+    def nbytes(self) -> int:
+        return sum(int(t.numel()) * t.element_size() for t in (self.local_idx, self.dict_ptr, self.dict))
+
+    @classmethod
+    def build(cls, csr: "DeviceCSR", chunks_per_slab: int = 8192) -> Optional["CompactCSR"]:
+        """Derive the compact copy on the device; ``None`` when a chunk references more than 65536 distinct gates
+        (positions are 16 bits; the standard kernel then stays in charge).  Per slab of chunks: key = (chunk, gate)
+        per pair, ``torch.unique`` (sorted) gives the dictionaries and every pair's position."""
+        torch = _native.torch_mod()
+        rows = _native.RG_COMPACT_ROWS
+        n_vox, n_pairs = csr.n_vox, csr.n_pairs
+        n_chunks = (n_vox + rows - 1) // rows
+        dev = csr.indptr.device
+        local = torch.empty(max(n_pairs, 1), dtype=torch.int16, device=dev)[:n_pairs]
+        counts = torch.zeros(n_chunks, dtype=torch.int64, device=dev)
+        chunk_pairs = torch.zeros(n_chunks, dtype=torch.int64, device=dev)
+        parts = []
+        for c0 in range(0, n_chunks, chunks_per_slab):
+            c1 = min(n_chunks, c0 + chunks_per_slab)
+            r0, r1 = c0 * rows, min(n_vox, c1 * rows)
+            ip = csr.indptr[r0:r1 + 1].to(torch.int64)
+            p0, p1 = int(ip[0]), int(ip[-1])
+            if p1 == p0:
+                continue
+            chunk_of_row = torch.arange(r1 - r0, device=dev, dtype=torch.int64) // rows
+            chunk_of_pair = torch.repeat_interleave(chunk_of_row, ip[1:] - ip[:-1], output_size=p1 - p0)
+            key = (chunk_of_pair << 32) | csr.gate_indices[p0:p1].to(torch.int64)
+            uniq, inverse = torch.unique(key, return_inverse=True)
+            cnt = torch.bincount(uniq >> 32, minlength=c1 - c0)
+            if int(cnt.max()) > 65536:
+                return None
+            start = torch.cumsum(cnt, 0) - cnt
+            local[p0:p1] = (inverse - start[chunk_of_pair]).to(torch.int16)   # bit pattern of the uint16 position
+            counts[c0:c1] = cnt
+            chunk_pairs[c0:c1] = torch.bincount(chunk_of_pair, minlength=c1 - c0)
+            parts.append((uniq & 0xFFFFFFFF).to(torch.int32))
+            del key, uniq, inverse, chunk_of_pair
+        dict_ptr = torch.zeros(n_chunks + 1, dtype=torch.int64, device=dev)
+        dict_ptr[1:] = torch.cumsum(counts, 0)
+        dict_ = torch.cat(parts) if parts else torch.zeros(1, dtype=torch.int32, device=dev)[:0]
+        # LDS window: the smallest size that leaves at most 0.1 % of the pairs to the per-pair fallback
+        window_cap = _native.RG_COMPACT_MAX_WINDOW
+        total = max(int(chunk_pairs.sum()), 1)
+        for cap in (1024, 2048, 4096, 8192):
+            if int(chunk_pairs[counts > cap].sum()) <= total // 1000:
+                window_cap = cap
+                break
+        return cls(local, dict_ptr, dict_, int(counts.max()) if n_chunks else 0, window_cap)
+
+
 class GridGeometry:
     """Precomputed gate -> voxel mapping in CSR form (``radar_grid/geometry.py:14-52``).
 
@@ -155,6 +220,19 @@ class GridGeometry:
     __hash__ = None
 
     # ---- device residency -----------------------------------------------------------------------
+    def device_compact(self, device=None) -> Optional[CompactCSR]:
+        """Compact copy of the device CSR (built once, cached); ``None`` when the geometry cannot be compacted."""
+        csr = self.device_csr(device)
+        cached = getattr(self, "_compact", None)
+        if cached is not None and cached[0] is csr:
+            return cached[1]
+        compact = CompactCSR.build(csr)
+        self._compact = (csr, compact)
+        if compact is not None:
+            logger.info(f"Compact CSR copy: {compact.nbytes() / 1e6:.1f} MB, {compact.n_dict:,} dictionary entries, "
+                        f"largest chunk {compact.max_dict}")
+        return compact
+
     def device_csr(self, device=None) -> DeviceCSR:
         """CSR in HBM: uploaded (and validated) once, then cached on the object."""
         dev = _native.device() if device is None else device

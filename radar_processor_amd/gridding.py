@@ -67,7 +67,9 @@ class CsrGridder:
     or graph-capture them.  All launches go to torch's current stream.
     """
 
-    def __init__(self, geometry: GridGeometry, n_gates: int, n_fields: int, device=None):
+    def __init__(self, geometry: GridGeometry, n_gates: int, n_fields: int, device=None, compact: bool = False):
+        """``compact``: for single-field passes use the compact device copy of the CSR (``rg_csr_compact_apply_f32``,
+        built and cached on the geometry the first time) when the geometry allows one; results are identical."""
         torch = _native.torch_mod()
         self.lib = _native.load_library()
         if not 1 <= n_fields <= _native.RG_MAX_FIELDS:
@@ -83,6 +85,7 @@ class CsrGridder:
             # the reference's fancy index (interpolate.py:74) raises the same way
             raise IndexError(f"index {self.csr.max_gate} is out of bounds for axis 0 with size {self.n_gates}")
         self.packed = torch.empty(max(self.n_gates, 1) * self.stride, dtype=torch.float32, device=self.dev)
+        self.compact = geometry.device_compact(self.dev) if (compact and self.n_fields == 1 and self.csr.n_pairs) else None
 
     def _check_fields(self, fields, masks, shared_mask):
         torch = _native.torch_mod()
@@ -111,6 +114,14 @@ class CsrGridder:
     def apply(self, out, fill_value: float = np.nan) -> None:
         """``rg_csr_apply_f32``: one pass over the CSR for all packed fields -> ``out[F, n_vox]``."""
         csr = self.csr
+        if self.compact is not None:
+            c = self.compact
+            _native.check(self.lib.rg_csr_compact_apply_f32(
+                _native.ptr(csr.indptr), int(csr.is_i64), _native.ptr(c.local_idx), _native.ptr(csr.weights),
+                _native.ptr(c.dict_ptr), _native.ptr(c.dict), self.n_vox, csr.n_pairs, _native.ptr(self.packed),
+                self.n_gates, float(np.float32(fill_value)), _native.ptr(out), c.window_cap, 0, _native.stream_ptr()),
+                "rg_csr_compact_apply_f32")
+            return
         _native.check(self.lib.rg_csr_apply_f32(
             _native.ptr(csr.indptr), int(csr.is_i64), _native.ptr(csr.gate_indices), _native.ptr(csr.weights),
             self.n_vox, csr.n_pairs, _native.ptr(self.packed), self.n_fields, self.stride, self.n_gates,
@@ -122,6 +133,16 @@ class CsrGridder:
         csr = self.csr
         ip = 8 if csr.is_i64 else 4
         return 8 * csr.n_pairs + ip * (self.n_vox + 1) + self.n_fields * (5 * self.n_gates + 4 * self.n_vox)
+
+    def compact_bytes(self) -> Optional[int]:
+        """Bytes one launch of the compact kernel must move: 16-bit position + weight per pair, the dictionaries and
+        their offsets, the row pointers, the field once, the grid once (``None`` without a compact copy)."""
+        if self.compact is None:
+            return None
+        csr, c = self.csr, self.compact
+        ip = 8 if csr.is_i64 else 4
+        return (6 * csr.n_pairs + 4 * c.n_dict + 8 * int(c.dict_ptr.numel()) + ip * (self.n_vox + 1)
+                + 5 * self.n_gates + 4 * self.n_vox)
 
 
 def grid_fields_device(geometry: GridGeometry, fields: Sequence, masks: Optional[Sequence] = None,
