@@ -12,7 +12,9 @@ Two layers:
 
 All fields handed to one call are gridded by ONE pass over the CSR (the reference re-reads the CSR per field,
 interpolate.py:137-140): the mask of every field is folded into its values and the fields are interleaved
-gate-major, so each (voxel, gate) pair costs a single gather.
+gate-major, so each (voxel, gate) pair costs a single gather.  Single-field passes over a large geometry switch, from
+the second use of that geometry on, to a compact device copy of the CSR (``rg_csr_compact_apply_f32``: 16-bit
+positions in a per-chunk gate dictionary, field window in LDS) -- identical results, about 25 % less time.
 """
 from __future__ import annotations
 
@@ -145,6 +147,25 @@ class CsrGridder:
                 + 5 * self.n_gates + 4 * self.n_vox)
 
 
+_COMPACT_MIN_PAIRS = 50_000_000     # below this a pass takes well under a millisecond either way
+
+
+def _use_compact(geometry: GridGeometry, dev) -> bool:
+    """Policy for single-field passes: the compact copy of the CSR costs a one-time conversion (about 0.2 s per
+    1e9 pairs) and 2.3 bytes per pair of HBM, so it is built the SECOND time a geometry grids a single field, when
+    the geometry is large enough to matter and the memory is there; once built it is always used."""
+    cached = getattr(geometry, "_compact", None)
+    if cached is not None and cached[0] is geometry.device_csr(dev):
+        return cached[1] is not None
+    uses = getattr(geometry, "_single_field_passes", 0) + 1
+    geometry._single_field_passes = uses
+    n_pairs = geometry.device_csr(dev).n_pairs
+    if uses < 2 or n_pairs < _COMPACT_MIN_PAIRS:
+        return False
+    free_b, _ = _native.torch_mod().cuda.mem_get_info(dev)
+    return free_b > 3.2 * n_pairs + (8 << 30)
+
+
 def grid_fields_device(geometry: GridGeometry, fields: Sequence, masks: Optional[Sequence] = None,
                        shared_mask=None, fill_value: float = np.nan, out=None):
     """Grid ``len(fields)`` device-resident fields with one CSR pass per group of up to 8.
@@ -179,7 +200,8 @@ def grid_fields_device(geometry: GridGeometry, fields: Sequence, masks: Optional
     with torch.cuda.device(dev):
         for f0 in range(0, n_fields, _native.RG_MAX_FIELDS):
             f1 = min(n_fields, f0 + _native.RG_MAX_FIELDS)
-            gridder = CsrGridder(geometry, n_gates, f1 - f0, device=dev)
+            gridder = CsrGridder(geometry, n_gates, f1 - f0, device=dev,
+                                 compact=n_fields == 1 and _use_compact(geometry, dev))
             gridder.pack(fields[f0:f1], masks[f0:f1], shared_mask)
             gridder.apply(out.view(n_fields, n_vox)[f0:f1], fill_value)
     return out.view(n_fields, nz, ny, nx)

@@ -210,3 +210,53 @@ def test_argument_validation_on_the_device_layer(rg):
         rg.roi_grid_fields_device(rg.RoiSearch(np.zeros(1, np.float32), np.zeros(1, np.float32), np.zeros(1, np.float32),
                                                (1, 1, 1), ((0, 0), (0, 0), (0, 0))), [torch.zeros(1, device=dev)],
                                   weighting="gaussian")
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1), (1, 3, 255), (2, 1, 257), (1, 5, 512), (3, 7, 300)])
+def test_compact_csr_edge_shapes(rg, tmp_path, shape):
+    """Compact copy on grids that are not a multiple of the 256-row chunk (a chunk then spans several y-rows or
+    levels), with int32 and int64 row pointers, empty rows and a custom fill value: bit-identical to the standard
+    kernel, both with the LDS window and on the per-pair fallback."""
+    import torch
+    from radar_processor_amd import _native
+    from radar_processor_amd.gridding import CsrGridder
+    from radar_processor_amd.grid_geometry import DeviceCSR, GridGeometry
+    gx, gy, gz, val, mask = _cloud(7, 6000)
+    nz, ny, nx = shape
+    limits = ((500.0, 500.0 if nz == 1 else 6000.0), (-3e3, -3e3 if ny == 1 else 9e3), (-15e3, -15e3 if nx == 1 else 15e3))
+    geom = rg.compute_grid_geometry(gx, gy, gz, shape, limits, str(tmp_path), min_radius=1500.0, beam_factor=0.05)
+    dev = torch.device("cuda")
+    f = torch.from_numpy(val).to(dev)
+    m = torch.from_numpy(mask.astype(np.uint8)).to(dev)
+    for as_i64 in (False, True):
+        csr = geom.device_csr(dev)
+        if as_i64:
+            g2 = GridGeometry.from_device(shape, limits, DeviceCSR(csr.indptr.to(torch.int64), csr.gate_indices, csr.weights,
+                                                                   csr.max_gate), 17000.0)
+        else:
+            g2 = geom
+        g_c = CsrGridder(g2, f.numel(), 1, device=dev, compact=True)
+        g_s = CsrGridder(g2, f.numel(), 1, device=dev)
+        if g_s.csr.n_pairs == 0:
+            assert g_c.compact is None
+            continue
+        assert g_c.compact is not None
+        g_c.pack([f], [m]); g_s.pack([f], [m])
+        want = torch.empty((1, g_s.n_vox), dtype=torch.float32, device=dev)
+        got = torch.empty_like(want)
+        g_s.apply(want, fill_value=-1.0)
+        g_c.apply(got, fill_value=-1.0)
+        assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+        c, k = g_c.compact, g_c.csr
+        lib = _native.load_library()
+        _native.check(lib.rg_csr_compact_apply_f32(
+            _native.ptr(k.indptr), int(k.is_i64), _native.ptr(c.local_idx), _native.ptr(k.weights), _native.ptr(c.dict_ptr),
+            _native.ptr(c.dict), g_c.n_vox, k.n_pairs, _native.ptr(g_c.packed), g_c.n_gates, -1.0, _native.ptr(got), 0, 0,
+            _native.stream_ptr()), "rg_csr_compact_apply_f32")
+        assert torch.equal(got.view(torch.int32), want.view(torch.int32))     # per-pair fallback, same tile size
+        _native.check(lib.rg_csr_compact_apply_f32(
+            _native.ptr(k.indptr), int(k.is_i64), _native.ptr(c.local_idx), _native.ptr(k.weights), _native.ptr(c.dict_ptr),
+            _native.ptr(c.dict), g_c.n_vox, k.n_pairs, _native.ptr(g_c.packed), g_c.n_gates, -1.0, _native.ptr(got),
+            c.window_cap, 256, _native.stream_ptr()), "rg_csr_compact_apply_f32")
+        # another tile size regroups the float32 partial sums: equal to rounding, not bit for bit
+        np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=2e-6, atol=1e-5)

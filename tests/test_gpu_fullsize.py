@@ -167,3 +167,45 @@ def test_c4_fused_gridder_invariants():
     assert float(seen.min()) >= float(valid.min()) - 1e-3 and float(seen.max()) <= float(valid.max()) + 1e-3
     # 8-fold symmetry of the geometry is NOT assumed; but the centre column must see the radar's own gates
     assert bool(torch.isfinite(out[0][0, 1000, 1000]))
+
+
+def test_c2_compact_csr_is_bit_identical(c2):
+    """rg_csr_compact_apply_f32 (16-bit dictionary positions, LDS field window) against rg_csr_apply_f32 on the full
+    config-2 geometry: the dictionaries reproduce the gate indices exactly and the grids agree bit for bit -- with the
+    geometry's own window size, with a window too small for most chunks, and with no window at all (every chunk on
+    the per-pair fallback)."""
+    from radar_processor_amd import _native
+    from radar_processor_amd.gridding import CsrGridder
+    rg, torch, geom, dev = c2["rg"], c2["torch"], c2["geom"], c2["dev"]
+    f, m = c2["fields"]["DBZH"], c2["masks"]["DBZH"]
+    g_c = CsrGridder(geom, f.numel(), 1, device=dev, compact=True)
+    g_s = CsrGridder(geom, f.numel(), 1, device=dev)
+    assert g_c.compact is not None and g_s.compact is None
+    csr, c = g_c.csr, g_c.compact
+    assert c.local_idx.numel() == csr.n_pairs and int(c.dict_ptr[-1]) == c.n_dict
+    assert g_c.compact_bytes() < 0.85 * g_c.algorithmic_bytes()
+    # decode a sample of pairs: dict[dict_ptr[chunk(row)] + position] == gate index
+    ip = csr.indptr.to(torch.int64)
+    rows = torch.randint(0, csr.n_vox, (20000,), device=dev)
+    rows = rows[(ip[rows + 1] - ip[rows]) > 0]
+    pairs = ip[rows] + (torch.rand(rows.numel(), device=dev) * (ip[rows + 1] - ip[rows]).float()).long()
+    pos = c.local_idx[pairs].to(torch.int64) & 0xFFFF
+    decoded = c.dict[c.dict_ptr[rows // _native.RG_COMPACT_ROWS] + pos]
+    assert bool((decoded == csr.gate_indices[pairs]).all())
+    # grids
+    g_c.pack([f], [m]); g_s.pack([f], [m])
+    want = torch.empty((1, g_s.n_vox), dtype=torch.float32, device=dev)
+    g_s.apply(want)
+    lib = _native.load_library()
+    for cap in (c.window_cap, 1024, 0):
+        got = torch.full_like(want, -7.0)
+        _native.check(lib.rg_csr_compact_apply_f32(
+            _native.ptr(csr.indptr), int(csr.is_i64), _native.ptr(c.local_idx), _native.ptr(csr.weights),
+            _native.ptr(c.dict_ptr), _native.ptr(c.dict), g_c.n_vox, csr.n_pairs, _native.ptr(g_c.packed), g_c.n_gates,
+            float("nan"), _native.ptr(got), cap, 0, _native.stream_ptr()), "rg_csr_compact_apply_f32")
+        assert bool(torch.equal(got.view(torch.int32), want.view(torch.int32))), f"window_cap={cap}"
+    # and through the gridder's own apply()
+    got = torch.empty_like(want)
+    g_c.apply(got, fill_value=-9999.0)
+    g_s.apply(want, fill_value=-9999.0)
+    assert bool(torch.equal(got.view(torch.int32), want.view(torch.int32)))
