@@ -50,11 +50,47 @@ __global__ __launch_bounds__(64 * kWaves) void csr_compact_kernel(
   f32x2* tile = tile_all[wv];
   f32x2* rowacc = rowacc_all[wv];
 
-  // ---- the chunk's field window: one gather per DISTINCT gate --------------------------------------------
   const long chunk = blockIdx.x;
   const long d0 = dict_ptr[chunk];
   const int nd = (int)(dict_ptr[chunk + 1] - d0);    // <= 65536: positions are 16 bits
   const bool windowed = nd <= window_cap;            // workgroup-uniform; the rare wider chunk gathers per pair
+  const int nd_last = nd > 0 ? nd - 1 : 0;
+  const int32_t* __restrict__ cdict = dict + d0;
+
+  const long r0 = chunk * RG_COMPACT_ROWS + (long)wv * 64;
+  const bool alive = r0 < n_vox;                     // wave-uniform; a dead wave still helps to fill the window
+  const long row = r0 + lane;
+  const long seg_b = alive ? (long)indptr[r0] : 0;
+  const long seg_e = alive ? (long)indptr[r0 + 64 < n_vox ? r0 + 64 : n_vox] : 0;
+  const int span = (int)(seg_e - seg_b);
+  const int rs_o = alive ? (int)((long)indptr[row < n_vox ? row : n_vox] - seg_b) : 0;
+  const int re_o = alive ? (int)((long)indptr[row + 1 < n_vox ? row + 1 : n_vox] - seg_b) : 0;
+  rowacc[lane] = (f32x2)(0.0f);
+
+  // Two register stages, loop unrolled by two, every load unconditional and range-checked against the chunk's last
+  // pair -- the same exact-wait-count pipeline as rg_csr_apply_f32, without a gather stage.
+  struct Stage {
+    int ci[IT];
+    float cw[IT];
+  };
+  Stage st[2];
+  const uint16_t* __restrict__ li = lidx + seg_b;
+  const float* __restrict__ wi = wts + seg_b;
+  const int lane2 = lane * 2, lane4 = lane * 4;
+  auto stream = [&](Stage& sg, int t) {   // t wave-uniform: the resources live in SGPRs
+    const rsrc_t ri = make_rsrc(li + t, ((long)span - t) * 2);
+    const rsrc_t rw = make_rsrc(wi + t, ((long)span - t) * 4);
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      sg.ci[it] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(ri, lane2 + it * 128, 0, 0);
+      sg.cw[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, lane4 + it * 256, 0, 0));
+    }
+  };
+  // the first two tiles are requested BEFORE the window is filled: the two latencies overlap
+  stream(st[0], 0);
+  stream(st[1], TILE);
+
+  // ---- the chunk's field window: one gather per DISTINCT gate --------------------------------------------
   if (windowed) {
     for (int i = threadIdx.x; i < nd; i += 64 * kWaves) {
       const unsigned g = (unsigned)dict[d0 + i];
@@ -62,40 +98,8 @@ __global__ __launch_bounds__(64 * kWaves) void csr_compact_kernel(
     }
   }
   __syncthreads();
-  const int nd_last = nd > 0 ? nd - 1 : 0;
-  const int32_t* __restrict__ cdict = dict + d0;
-
-  const long r0 = chunk * RG_COMPACT_ROWS + (long)wv * 64;
-  if (r0 >= n_vox) return;  // wave-uniform (after the only barrier)
-  const long row = r0 + lane;
-  const long seg_b = (long)indptr[r0];
-  const long seg_e = (long)indptr[r0 + 64 < n_vox ? r0 + 64 : n_vox];
-  const int span = (int)(seg_e - seg_b);
-  const int rs_o = (int)((long)indptr[row < n_vox ? row : n_vox] - seg_b);
-  const int re_o = (int)((long)indptr[row + 1 < n_vox ? row + 1 : n_vox] - seg_b);
-  rowacc[lane] = (f32x2)(0.0f);
 
   if (span > 0) {
-    // Two register stages, loop unrolled by two, every load unconditional and range-checked against the chunk's
-    // last pair -- the same exact-wait-count pipeline as rg_csr_apply_f32, without a gather stage.
-    struct Stage {
-      int ci[IT];
-      float cw[IT];
-    };
-    Stage st[2];
-    const uint16_t* __restrict__ li = lidx + seg_b;
-    const float* __restrict__ wi = wts + seg_b;
-    const int lane2 = lane * 2, lane4 = lane * 4;
-
-    auto stream = [&](Stage& sg, int t) {   // t wave-uniform: the resources live in SGPRs
-      const rsrc_t ri = make_rsrc(li + t, ((long)span - t) * 2);
-      const rsrc_t rw = make_rsrc(wi + t, ((long)span - t) * 4);
-#pragma unroll
-      for (int it = 0; it < IT; ++it) {
-        sg.ci[it] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(ri, lane2 + it * 128, 0, 0);
-        sg.cw[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, lane4 + it * 256, 0, 0));
-      }
-    };
     auto step = [&](int t, Stage& cur) {
       // ---- products of tile t -> LDS (values come from the window) -----------------------------------
       float val[IT];
@@ -157,8 +161,6 @@ __global__ __launch_bounds__(64 * kWaves) void csr_compact_kernel(
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
 
-    stream(st[0], 0);
-    stream(st[1], TILE);
     for (int t = 0; t < span;) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -183,10 +185,10 @@ int launch(int tile, int window_cap, const void* indptr, const uint16_t* lidx, c
   hipLaunchKernelGGL((csr_compact_kernel<IndT, TILE_>), dim3((unsigned)chunks), dim3(64 * kWaves),                    \
                      (size_t)window_cap * sizeof(float), s, static_cast<const IndT*>(indptr), lidx, wts, dict_ptr, dict, \
                      n_vox, packed, (unsigned)(n_gates - 1), fill, window_cap, out)
-  switch (tile) {
+  switch (tile) {   // the default must be the tile of rg_csr_apply_f32's single-field kernel: same partial sums
     case 256: RG_K1C(256); break;
-    case 384: RG_K1C(384); break;
-    default: RG_K1C(512); break;
+    case 512: RG_K1C(512); break;
+    default: RG_K1C(384); break;
   }
 #undef RG_K1C
   return rg::check_launch("rg_csr_compact_apply_f32");
