@@ -209,3 +209,21 @@ def test_c2_compact_csr_is_bit_identical(c2):
     g_c.apply(got, fill_value=-9999.0)
     g_s.apply(want, fill_value=-9999.0)
     assert bool(torch.equal(got.view(torch.int32), want.view(torch.int32)))
+
+
+def test_c2_single_field_passes_switch_to_the_compact_copy(c2):
+    """gridding._use_compact: the first single-field pass of a geometry runs the standard kernel, the second builds the
+    compact copy and uses it from then on; multi-field passes never do.  Same bits every time."""
+    rg, torch, dev = c2["rg"], c2["torch"], c2["dev"]
+    from radar_processor_amd.grid_geometry import GridGeometry
+    geom = GridGeometry.from_device(c2["geom"].grid_shape, c2["geom"].grid_limits, c2["geom"].device_csr(dev), 17000.0)
+    f, m = c2["fields"]["ZDR"], c2["masks"]["ZDR"]
+    first = rg.grid_fields_device(geom, [f], [m]).clone()
+    assert getattr(geom, "_compact", None) is None
+    rg.grid_fields_device(geom, [f, c2["fields"]["DBZH"]], [m, None])
+    assert getattr(geom, "_compact", None) is None
+    second = rg.grid_fields_device(geom, [f], [m]).clone()
+    assert geom._compact is not None and geom._compact[1] is not None
+    third = rg.grid_fields_device(geom, [f], [m])
+    assert torch.equal(first.view(torch.int32), second.view(torch.int32))
+    assert torch.equal(first.view(torch.int32), third.view(torch.int32))
