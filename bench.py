@@ -80,7 +80,10 @@ def cpu_baseline(geom, vol, field_name, n_vox_total, max_pairs):
     v0, v1 = r0 * nx, r1 * nx
     p0, p1 = int(ip_rows[r0]), int(ip_rows[r1])
     indptr = (csr.indptr[v0:v1 + 1].cpu().numpy().astype(np.int64) - p0)
-    gidx = csr.gate_indices[p0:p1].cpu().numpy()
+    if csr.gate_indices is not None:
+        gidx = csr.gate_indices[p0:p1].cpu().numpy()
+    else:                                          # compact-only geometry: rebuild the sample's index array
+        gidx = geom.device_compact().decode(csr, v0, v1).cpu().numpy()
     wts = csr.weights[p0:p1].cpu().numpy()
     shape = (1, r1 - r0, nx)
     data, mask = oracle.merge_masks(vol.fields[field_name])
@@ -175,10 +178,13 @@ def main():
         search = None
         import tempfile
         with tempfile.TemporaryDirectory() as tmp:
-            geom = rg.compute_grid_geometry(vol.gate_x, vol.gate_y, vol.gate_z, shape, limits, tmp)
-        want_compact = n_ff == 1 and not args.no_compact
-        if want_compact:     # the compact copy needs ~2.3 bytes per pair next to the 8 of the standard arrays
-            free_b, _ = torch.cuda.mem_get_info(dev)
+            # single field-volume passes use the compact copy of the CSR; 'auto' keeps the reference's index array
+            # next to it when both fit and builds the copy alone otherwise (config 4: 33 G pairs)
+            want_compact = n_ff == 1 and not args.no_compact
+            geom = rg.compute_grid_geometry(vol.gate_x, vol.gate_y, vol.gate_z, shape, limits, tmp,
+                                            layout="auto" if want_compact else "csr")
+        if want_compact and geom.device_csr(dev).gate_indices is not None:
+            free_b, _ = torch.cuda.mem_get_info(dev)              # room for the copy (2.3 bytes per pair + scratch)?
             want_compact = free_b > 3.2 * geom.n_pairs() + (8 << 30)
         gridder = CsrGridder(geom, n_gates, n_ff, device=dev, compact=want_compact)
         n_pairs = gridder.csr.n_pairs

@@ -118,6 +118,19 @@ class RoiSearch:
         return float(min(max(cell, 0.25 * self.min_radius, 25.0), 8.0 * max(self.min_radius, 1.0) + 2000.0))
 
     # ------------------------------------------------------------------------------------------------
+    def count_pairs(self) -> int:
+        """Total number of (voxel, gate) pairs of the geometry (one count pass, nothing is kept)."""
+        torch = _native.torch_mod()
+        lib = _native.load_library()
+        nz, ny, nx = self.grid_shape
+        with torch.cuda.device(self.dev):
+            counts = torch.zeros(nz * ny * nx + 1, dtype=torch.int32, device=self.dev)
+            _native.check(lib.rg_geom_count_f32(
+                _native.ptr(self.sorted_gates), _native.ptr(self.cell_start), self.cells, _native.ptr(self.xc),
+                _native.ptr(self.yc), _native.ptr(self.zc), nz, ny, nx, self.min_radius, self.beam_factor,
+                _native.ptr(counts), _native.stream_ptr()), "rg_geom_count_f32")
+            return int(counts.sum(dtype=torch.int64).item())
+
     def build_csr(self, weighting: str = "barnes2") -> DeviceCSR:
         torch = _native.torch_mod()
         lib = _native.load_library()
@@ -151,6 +164,93 @@ class RoiSearch:
         return DeviceCSR(indptr, gate_idx, weights, max_gate)
 
 
+def _build_compact_only(search: "RoiSearch", weighting: str, pairs_per_slab: int = 1_200_000_000,
+                        chunks_per_pass: int = 8192):
+    """Count -> scan -> per slab of whole grid levels: fill the slab's gate indices into a scratch buffer, derive the
+    dictionaries and 16-bit positions of the 256-row chunks it completes, drop the scratch (the rows of a chunk that
+    straddles the slab boundary are carried into the next slab).  The int32 index array of the whole grid -- half of
+    the standard CSR -- never exists, so a geometry of P pairs needs 6.3*P bytes instead of 8*P (+2.3*P for the copy).
+    Returns ``(DeviceCSR without gate_indices, CompactCSR)`` or ``None`` when a chunk holds more than 65536 distinct
+    gates."""
+    from .grid_geometry import CompactCSR
+    torch = _native.torch_mod()
+    lib = _native.load_library()
+    nz, ny, nx = search.grid_shape
+    n_xy = ny * nx
+    rows = _native.RG_COMPACT_ROWS
+    n_vox = nz * n_xy
+    dev = search.dev
+    with torch.cuda.device(dev):
+        stream = _native.stream_ptr()
+        counts = torch.zeros(n_vox + 1, dtype=torch.int32, device=dev)
+        _native.check(lib.rg_geom_count_f32(
+            _native.ptr(search.sorted_gates), _native.ptr(search.cell_start), search.cells, _native.ptr(search.xc),
+            _native.ptr(search.yc), _native.ptr(search.zc), nz, ny, nx, search.min_radius, search.beam_factor,
+            _native.ptr(counts), stream), "rg_geom_count_f32")
+        indptr = torch.empty(n_vox + 1, dtype=torch.int64, device=dev)
+        ws_bytes = int(lib.rg_scan_workspace_bytes(n_vox))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        _native.check(lib.rg_scan_counts_i64(_native.ptr(counts), n_vox, _native.ptr(indptr), _native.ptr(ws), ws_bytes,
+                                             stream), "rg_scan_counts_i64")
+        del counts, ws
+        level_ptr = indptr[::n_xy].cpu().numpy()                 # pair offset at the start of every grid level
+        n_pairs = int(level_ptr[-1])
+        weights = torch.empty(max(n_pairs, 1), dtype=torch.float32, device=dev)[:n_pairs]
+        local = torch.empty(max(n_pairs, 1), dtype=torch.int16, device=dev)[:n_pairs]
+        n_chunks = (n_vox + rows - 1) // rows
+        c_counts = torch.zeros(n_chunks, dtype=torch.int64, device=dev)
+        c_pairs = torch.zeros(n_chunks, dtype=torch.int64, device=dev)
+        parts = []
+        max_gate = -1
+        done_row = 0                                              # rows below are compacted; always a chunk boundary
+        carry = torch.empty(0, dtype=torch.int32, device=dev)    # gate indices of rows [done_row, first row of the slab)
+        iz0 = 0
+        while iz0 < nz:
+            iz1 = iz0 + 1
+            while iz1 < nz and level_ptr[iz1 + 1] - level_ptr[iz0] <= pairs_per_slab:
+                iz1 += 1
+            p0, p1 = int(level_ptr[iz0]), int(level_ptr[iz1])
+            n_carry = int(carry.numel())
+            scratch = torch.empty(max(n_carry + p1 - p0, 1), dtype=torch.int32, device=dev)[:n_carry + p1 - p0]
+            scratch[:n_carry] = carry
+            if p1 > p0:
+                # the fill kernel writes at absolute pair positions: shift the index pointer so that they land behind
+                # the carried rows in the scratch buffer; the weights go straight to their final place
+                _native.check(lib.rg_geom_fill_f32(
+                    _native.ptr(search.sorted_gates), _native.ptr(search.cell_start), search.cells, _native.ptr(search.xc),
+                    _native.ptr(search.yc), _native.ptr(search.zc) + 4 * iz0, iz1 - iz0, ny, nx, search.min_radius,
+                    search.beam_factor, _native.WEIGHTINGS[weighting], _native.ptr(indptr) + 8 * iz0 * n_xy,
+                    _native.ptr(scratch) + 4 * n_carry - 4 * p0, _native.ptr(weights), stream), "rg_geom_fill_f32")
+            end_row = n_vox if iz1 == nz else (iz1 * n_xy // rows) * rows
+            if end_row > done_row:
+                ip = indptr[done_row:end_row + 1]
+                q0, q1 = int(ip[0]), int(ip[-1])                  # q0 == p0 - n_carry
+                c0, c1 = done_row // rows, (end_row + rows - 1) // rows
+                if q1 > q0:
+                    max_gate = max(max_gate, int(scratch[:q1 - q0].max().item()))
+                    for s0 in range(c0, c1, chunks_per_pass):     # torch.unique needs ~50 bytes of scratch per pair
+                        s1 = min(c1, s0 + chunks_per_pass)
+                        ip_s = indptr[s0 * rows:min(end_row, s1 * rows) + 1]
+                        a, b = int(ip_s[0]) - q0, int(ip_s[-1]) - q0
+                        if b == a:
+                            continue
+                        part = CompactCSR._slab(ip_s, scratch[a:b], s1 - s0, local[q0 + a:q0 + b], c_counts[s0:s1],
+                                                c_pairs[s0:s1])
+                        if part is None:
+                            return None
+                        parts.append(part)
+                carry = scratch[q1 - q0:].clone()
+                done_row = end_row
+            else:
+                carry = scratch
+            del scratch
+            iz0 = iz1
+        compact = CompactCSR._finish(local, c_counts, c_pairs, parts)
+        if n_pairs <= _INT32_MAX:
+            indptr = indptr.to(torch.int32)
+    return DeviceCSR(indptr, None, weights, max_gate), compact
+
+
 def compute_grid_geometry(
     gate_x: np.ndarray,
     gate_y: np.ndarray,
@@ -164,6 +264,7 @@ def compute_grid_geometry(
     weighting: str = "barnes2",
     toa: float = 17000.0,
     n_workers: Optional[int] = None,
+    layout: str = "csr",
 ) -> GridGeometry:
     """Precompute which gates contribute to each voxel and with what weight
     (``radar_grid/compute.py:106-284``; same signature).
@@ -172,6 +273,12 @@ def compute_grid_geometry(
     raises ``ValueError`` otherwise, compute.py:173-174) but nothing is written to it, and there is no worker
     pool -- the build runs on the GPU.  The result is device resident; ``.indptr`` / ``.gate_indices`` /
     ``.weights`` copy to the host on first access (``save_geometry`` does that).
+
+    ``layout`` (build-specific): ``"csr"`` keeps the reference's three arrays in HBM; ``"auto"`` does so whenever
+    they and their compact copy fit the free memory, and otherwise falls to ``"compact"``, which keeps
+    ``indptr``, ``weights`` and the compact copy of the gate indices only (``grid_geometry.CompactCSR``, 6.3 instead
+    of 8 bytes per pair) -- for single-field gridding of geometries too large to hold both; ``.gate_indices`` is then
+    rebuilt from the copy when somebody asks for it.
 
     Reference quirks kept on purpose: ``radar_altitude`` is subtracted from ``gate_z``
     in float32 (compute.py:182), the returned geometry does not carry it (compute.py:277-284 => 0.0), and
@@ -189,6 +296,23 @@ def compute_grid_geometry(
     logger.info(f"TOA filter: {search.n_binned:,} of {search.n_gates:,} gates kept (below {toa}m and within reach "
                 f"of the grid); cell size {search.cell_size:.0f} m")
     logger.info(f"Processing {nz} z-levels on {search.dev}...")
+    if layout not in ("csr", "compact", "auto"):
+        raise ValueError("layout must be 'csr', 'compact' or 'auto'")
+    if layout == "auto":
+        # the reference's arrays whenever they fit (8 bytes per pair; their compact copy is added later if there is
+        # room for it), the compact layout alone (6.3 bytes per pair) only for geometries that would not fit otherwise
+        n_pairs = search.count_pairs()
+        free_b, _ = _native.torch_mod().cuda.mem_get_info(search.dev)
+        layout = "csr" if 8.1 * n_pairs + (10 << 30) <= free_b else "compact"
+        logger.info(f"{n_pairs:,} pairs, {free_b / 1e9:.0f} GB free -> layout '{layout}'")
+    if layout == "compact":
+        built = _build_compact_only(search, weighting)
+        if built is not None:
+            csr, compact = built
+            logger.info(f"Geometry complete ({csr.n_pairs:,} total pairs, compact layout: {compact.n_dict:,} dictionary "
+                        f"entries).")
+            return GridGeometry.from_device(grid_shape, grid_limits, csr, toa, compact=compact)
+        logger.info("compact layout not possible for this grid; building the standard CSR")
     csr = search.build_csr(weighting)
     logger.info(f"Geometry complete ({csr.n_pairs:,} total pairs).")
     return GridGeometry.from_device(grid_shape, grid_limits, csr, toa)

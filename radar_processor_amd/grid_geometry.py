@@ -29,15 +29,16 @@ class DeviceCSR:
 
     def __init__(self, indptr, gate_indices, weights, max_gate: int):
         self.indptr = indptr
-        self.gate_indices = gate_indices
+        self.gate_indices = gate_indices   # None when the geometry was built compact-only (see CompactCSR)
         self.weights = weights
         self.n_vox = int(indptr.shape[0]) - 1
-        self.n_pairs = int(gate_indices.shape[0])
+        self.n_pairs = int(weights.shape[0])
         self.max_gate = int(max_gate)   # largest gate index referenced (-1 when there are no pairs)
         self.is_i64 = indptr.dtype == _native.torch_mod().int64
 
     def nbytes(self) -> int:
-        return sum(int(t.numel()) * t.element_size() for t in (self.indptr, self.gate_indices, self.weights))
+        return sum(int(t.numel()) * t.element_size() for t in (self.indptr, self.gate_indices, self.weights)
+                   if t is not None)
 
 
 class CompactCSR:
@@ -79,19 +80,40 @@ class CompactCSR:
             p0, p1 = int(ip[0]), int(ip[-1])
             if p1 == p0:
                 continue
-            chunk_of_row = torch.arange(r1 - r0, device=dev, dtype=torch.int64) // rows
-            chunk_of_pair = torch.repeat_interleave(chunk_of_row, ip[1:] - ip[:-1], output_size=p1 - p0)
-            key = (chunk_of_pair << 32) | csr.gate_indices[p0:p1].to(torch.int64)
-            uniq, inverse = torch.unique(key, return_inverse=True)
-            cnt = torch.bincount(uniq >> 32, minlength=c1 - c0)
-            if int(cnt.max()) > 65536:
+            part = cls._slab(ip, csr.gate_indices[p0:p1], c1 - c0, local[p0:p1], counts[c0:c1], chunk_pairs[c0:c1])
+            if part is None:
                 return None
-            start = torch.cumsum(cnt, 0) - cnt
-            local[p0:p1] = (inverse - start[chunk_of_pair]).to(torch.int16)   # bit pattern of the uint16 position
-            counts[c0:c1] = cnt
-            chunk_pairs[c0:c1] = torch.bincount(chunk_of_pair, minlength=c1 - c0)
-            parts.append((uniq & 0xFFFFFFFF).to(torch.int32))
-            del key, uniq, inverse, chunk_of_pair
+            parts.append(part)
+        return cls._finish(local, counts, chunk_pairs, parts)
+
+    @staticmethod
+    def _slab(ip, gate_idx, n_chunks: int, local_out, counts_out, pairs_out):
+        """One slab of whole chunks: ``ip`` = its int64 row pointers (absolute), ``gate_idx`` = the gate indices of
+        its pairs.  Fills the slab's positions / counts and returns its dictionaries, or ``None`` when a chunk holds
+        more than 65536 distinct gates."""
+        torch = _native.torch_mod()
+        rows = _native.RG_COMPACT_ROWS
+        n_rows = int(ip.shape[0]) - 1
+        n_p = int(gate_idx.shape[0])
+        chunk_of_row = torch.arange(n_rows, device=ip.device, dtype=torch.int64) // rows
+        chunk_of_pair = torch.repeat_interleave(chunk_of_row, ip[1:] - ip[:-1], output_size=n_p)
+        key = (chunk_of_pair << 32) | gate_idx.to(torch.int64)
+        uniq, inverse = torch.unique(key, return_inverse=True)
+        del key
+        cnt = torch.bincount(uniq >> 32, minlength=n_chunks)
+        if int(cnt.max()) > 65536:
+            return None
+        start = torch.cumsum(cnt, 0) - cnt
+        local_out.copy_((inverse - start[chunk_of_pair]).to(torch.int16))   # bit pattern of the uint16 position
+        counts_out.copy_(cnt)
+        pairs_out.copy_(torch.bincount(chunk_of_pair, minlength=n_chunks))
+        return (uniq & 0xFFFFFFFF).to(torch.int32)
+
+    @classmethod
+    def _finish(cls, local, counts, chunk_pairs, parts) -> "CompactCSR":
+        torch = _native.torch_mod()
+        dev = counts.device
+        n_chunks = int(counts.shape[0])
         dict_ptr = torch.zeros(n_chunks + 1, dtype=torch.int64, device=dev)
         dict_ptr[1:] = torch.cumsum(counts, 0)
         dict_ = torch.cat(parts) if parts else torch.zeros(1, dtype=torch.int32, device=dev)[:0]
@@ -103,6 +125,29 @@ class CompactCSR:
                 window_cap = cap
                 break
         return cls(local, dict_ptr, dict_, int(counts.max()) if n_chunks else 0, window_cap)
+
+    def decode(self, csr: "DeviceCSR", row0: int = 0, row1: Optional[int] = None, chunks_per_slab: int = 8192):
+        """The standard int32 gate indices of rows ``[row0, row1)`` (default: all), rebuilt from positions and
+        dictionaries; device tensor of ``indptr[row1] - indptr[row0]`` entries."""
+        torch = _native.torch_mod()
+        rows = _native.RG_COMPACT_ROWS
+        dev = csr.indptr.device
+        row1 = csr.n_vox if row1 is None else row1
+        q0, q1 = int(csr.indptr[row0]), int(csr.indptr[row1])
+        out = torch.empty(max(q1 - q0, 1), dtype=torch.int32, device=dev)[:q1 - q0]
+        c_lo, c_hi = row0 // rows, (row1 + rows - 1) // rows
+        for c0 in range(c_lo, c_hi, chunks_per_slab):
+            c1 = min(c_hi, c0 + chunks_per_slab)
+            r0, r1 = max(c0 * rows, row0), min(csr.n_vox, c1 * rows, row1)
+            ip = csr.indptr[r0:r1 + 1].to(torch.int64)
+            p0, p1 = int(ip[0]), int(ip[-1])
+            if p1 == p0:
+                continue
+            chunk_of_row = torch.arange(r0, r1, device=dev, dtype=torch.int64) // rows
+            chunk_of_pair = torch.repeat_interleave(chunk_of_row, ip[1:] - ip[:-1], output_size=p1 - p0)
+            pos = self.local_idx[p0:p1].to(torch.int64) & 0xFFFF
+            out[p0 - q0:p1 - q0] = self.dict[self.dict_ptr[chunk_of_pair] + pos]
+        return out
 
 
 class GridGeometry:
@@ -126,9 +171,14 @@ class GridGeometry:
 
     # ---- construction from device-resident arrays (GPU builder) -----------------------------------
     @classmethod
-    def from_device(cls, grid_shape, grid_limits, csr: DeviceCSR, toa: float, radar_altitude: float = 0.0):
+    def from_device(cls, grid_shape, grid_limits, csr: DeviceCSR, toa: float, radar_altitude: float = 0.0,
+                    compact: Optional["CompactCSR"] = None):
         g = cls(grid_shape, grid_limits, None, None, None, toa, radar_altitude)
         g._dev = csr
+        if compact is not None:
+            g._compact = (csr, compact)
+        elif csr.gate_indices is None:
+            raise ValueError("a CSR without gate indices needs its compact copy")
         return g
 
     # ---- host views (lazy) -----------------------------------------------------------------------
@@ -138,7 +188,10 @@ class GridGeometry:
             if self._dev is None:
                 raise AttributeError(f"GridGeometry has no {name}")
             logger.debug("copying %s to the host", name)
-            arr = getattr(self._dev, name).cpu().numpy()
+            dev_arr = getattr(self._dev, name)
+            if dev_arr is None:      # compact-only geometry: rebuild the reference's index array from the copy
+                dev_arr = self._compact[1].decode(self._dev)
+            arr = dev_arr.cpu().numpy()
             setattr(self, "_" + name, arr)
         return arr
 
@@ -241,6 +294,8 @@ class GridGeometry:
         torch = _native.torch_mod()
         if self._dev is not None:   # resident on another GPU: replicate device-to-device
             src = self._dev
+            if src.gate_indices is None:
+                raise _native.NativeError("a compact-only geometry cannot be replicated to another GPU; rebuild it there")
             self._dev = DeviceCSR(src.indptr.to(dev), src.gate_indices.to(dev), src.weights.to(dev), src.max_gate)
             return self._dev
         indptr = np.ascontiguousarray(self._indptr)

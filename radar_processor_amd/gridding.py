@@ -87,7 +87,16 @@ class CsrGridder:
             # the reference's fancy index (interpolate.py:74) raises the same way
             raise IndexError(f"index {self.csr.max_gate} is out of bounds for axis 0 with size {self.n_gates}")
         self.packed = torch.empty(max(self.n_gates, 1) * self.stride, dtype=torch.float32, device=self.dev)
-        self.compact = geometry.device_compact(self.dev) if (compact and self.n_fields == 1 and self.csr.n_pairs) else None
+        compact_only = self.csr.gate_indices is None
+        if compact_only and self.n_fields != 1:
+            raise _native.NativeError("this geometry holds only the compact copy of its CSR, which serves single-field "
+                                      "passes; build it with compute_grid_geometry() for fused multi-field passes")
+        self.compact = (geometry.device_compact(self.dev)
+                        if ((compact or compact_only) and self.n_fields == 1 and self.csr.n_pairs) else None)
+        if self.compact is not None and not compact_only and self.compact.window_cap > _COMPACT_MAX_USEFUL_WINDOW:
+            # chunks with this many distinct gates (dense scans on coarse grids) leave too little LDS for occupancy:
+            # measured slower than the standard kernel (config 4: 52.8 vs 49.1 ms)
+            self.compact = None
 
     def _check_fields(self, fields, masks, shared_mask):
         torch = _native.torch_mod()
@@ -148,6 +157,7 @@ class CsrGridder:
 
 
 _COMPACT_MIN_PAIRS = 50_000_000     # below this a pass takes well under a millisecond either way
+_COMPACT_MAX_USEFUL_WINDOW = 4096   # LDS window (values) beyond which the compact kernel loses to the standard one
 
 
 def _use_compact(geometry: GridGeometry, dev) -> bool:

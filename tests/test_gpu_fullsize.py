@@ -227,3 +227,34 @@ def test_c2_single_field_passes_switch_to_the_compact_copy(c2):
     third = rg.grid_fields_device(geom, [f], [m])
     assert torch.equal(first.view(torch.int32), second.view(torch.int32))
     assert torch.equal(first.view(torch.int32), third.view(torch.int32))
+
+
+def test_c2_compact_only_layout(c2, tmp_path):
+    """compute_grid_geometry(layout="compact"): the int32 index array is never materialised for the whole grid; row
+    pointers and weights equal the standard build bit for bit, the decoded indices equal its gate_indices, gridding
+    gives the same bits, multi-field passes are refused, and layout="auto" keeps the standard arrays when they fit."""
+    rg, torch, dev, vol, cfg = c2["rg"], c2["torch"], c2["dev"], c2["vol"], c2["cfg"]
+    std = c2["geom"].device_csr(dev)
+    geom = rg.compute_grid_geometry(vol.gate_x, vol.gate_y, vol.gate_z, cfg["grid_shape"], cfg["grid_limits"],
+                                    str(tmp_path), layout="compact")
+    csr = geom.device_csr(dev)
+    assert csr.gate_indices is None and csr.n_pairs == std.n_pairs and csr.max_gate == std.max_gate
+    assert torch.equal(csr.indptr.to(torch.int64), std.indptr.to(torch.int64))
+    assert torch.equal(csr.weights.view(torch.int32), std.weights.view(torch.int32))
+    compact = geom.device_compact(dev)
+    assert torch.equal(compact.decode(csr), std.gate_indices)
+    nx = cfg["grid_shape"][2]
+    r0, r1 = 7 * nx + 13, 1234 * nx + 5          # a row range that is not aligned to the 256-row chunks
+    assert torch.equal(compact.decode(csr, r0, r1), std.gate_indices[int(std.indptr[r0]):int(std.indptr[r1])])
+    f, m = c2["fields"]["DBZH"], c2["masks"]["DBZH"]
+    want = rg.grid_fields_device(c2["geom"], [f], [m])
+    got = rg.grid_fields_device(geom, [f], [m])
+    assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+    with pytest.raises(rg.NativeError):
+        rg.grid_fields_device(geom, [f, f], [m, m])
+    auto = rg.compute_grid_geometry(vol.gate_x, vol.gate_y, vol.gate_z, cfg["grid_shape"], cfg["grid_limits"],
+                                    str(tmp_path), layout="auto")
+    assert auto.device_csr(dev).gate_indices is not None
+    with pytest.raises(ValueError):
+        rg.compute_grid_geometry(vol.gate_x, vol.gate_y, vol.gate_z, cfg["grid_shape"], cfg["grid_limits"],
+                                 str(tmp_path), layout="coo")
