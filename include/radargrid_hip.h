@@ -304,6 +304,18 @@ int rg_csr_compact_apply_f32(const void* indptr, int32_t indptr_is_i64, const ui
                              const float* packed, int64_t n_gates, float fill_value, float* out, int32_t window_cap,
                              int32_t tile, rg_stream_t stream);
 
+/* Building the compact copy from a standard CSR (or from one slab of it: pass indptr + first_row and pointers shifted
+ * accordingly; the row pointers hold absolute pair positions).  rg_csr_compact_count: chunk_counts[c] = distinct
+ * gates of chunk c (65537 = more than the 16-bit positions can address: not compactable), chunk_rounds[c] = hashing
+ * rounds the chunk needed (opaque, handed to the fill pass).  The caller turns the counts into dict_ptr
+ * (rg_scan_counts_i64, chunk_counts needs one spare entry) and calls rg_csr_compact_fill, which writes
+ * dict[dict_ptr[c] ..] and local_idx[p] for every pair.  Dictionary order is unspecified. */
+int rg_csr_compact_count(const void* indptr, int32_t indptr_is_i64, const int32_t* gate_idx, int64_t n_rows,
+                         int32_t* chunk_counts, uint8_t* chunk_rounds, rg_stream_t stream);
+int rg_csr_compact_fill(const void* indptr, int32_t indptr_is_i64, const int32_t* gate_idx, int64_t n_rows,
+                        const int64_t* dict_ptr, const uint8_t* chunk_rounds, int32_t* dict, uint16_t* local_idx,
+                        rg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

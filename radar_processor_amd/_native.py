@@ -73,6 +73,9 @@ SIGNATURES = {
                                     c_int32, c_int32, c_double, c_double, c_void_p, c_void_p]),
     "rg_csr_compact_apply_f32": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                            c_void_p, c_int64, c_float, c_void_p, c_int32, c_int32, c_void_p]),
+    "rg_csr_compact_count": (c_int32, [c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "rg_csr_compact_fill": (c_int32, [c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p]),
     "rg_scan_workspace_bytes": (c_int64, [c_int64]),
     "rg_scan_counts_i64": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
     "rg_geom_fill_f32": (c_int32, [c_void_p, c_void_p, POINTER(CellGrid), c_void_p, c_void_p, c_void_p, c_int32,

@@ -219,3 +219,173 @@ extern "C" int rg_csr_compact_apply_f32(const void* indptr, int32_t indptr_is_i6
   return launch<int32_t>(tile, window_cap, indptr, local_idx, weights, dict_ptr, dict, n_vox, packed, n_gates, fill_value,
                          out, s);
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Building the compact copy: the distinct gates of every chunk and each pair's position among them.
+// One workgroup per chunk keeps an open-addressing hash set of gate indices in LDS.  Chunks whose dictionary would
+// overload the table are processed in R = 2, 4, ... 32 rounds, round r taking the gates of one residue class of a
+// second hash, so any chunk up to 65536 distinct gates is handled with 32 KiB of LDS.
+//   count pass: distinct gates per chunk (and the rounds it needed)   -> rg_scan_counts_i64 gives dict_ptr
+//   fill pass : same rounds; occupied slots get consecutive positions (block prefix sum), the dictionary is written,
+//               and a second sweep over the round's pairs looks every gate up and stores its 16-bit position.
+// Positions depend on the insertion order (not reproducible run to run); the gridding result does not.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int kSlots = 8192;          // hash slots per workgroup (32 KiB)
+constexpr int kMaxLoad = 6144;        // distinct gates one round may insert
+constexpr int kBuildThreads = 256;
+constexpr int kMaxRounds = 32;
+
+__device__ __forceinline__ unsigned slot_hash(unsigned g) { return (g * 2654435761u) >> 19; }      // 13 bits
+__device__ __forceinline__ unsigned round_hash(unsigned g) { return (g * 0x85EBCA6Bu) >> 27; }     // 5 bits
+
+// Inserts the gates of residue class `r` (of `rounds`) among pairs [p0, p1).  Returns false when the table overloads.
+template <typename IndT>
+__device__ bool insert_round(const int32_t* __restrict__ gidx, long p0, long p1, int rounds, int r, int* table,
+                             int* s_count, int* s_overflow) {
+  for (int i = threadIdx.x; i < kSlots; i += kBuildThreads) table[i] = -1;
+  if (threadIdx.x == 0) { *s_count = 0; *s_overflow = 0; }
+  __syncthreads();
+  for (long p = p0 + threadIdx.x; p < p1; p += kBuildThreads) {
+    const int g = gidx[p];
+    if (rounds > 1 && (int)(round_hash((unsigned)g) & (unsigned)(rounds - 1)) != r) continue;
+    unsigned h = slot_hash((unsigned)g);
+    while (true) {
+      const int seen = *(volatile int*)&table[h];   // other lanes insert concurrently
+      if (seen == g) break;
+      if (seen == -1) {
+        if (*(volatile int*)s_overflow) break;
+        const int old = atomicCAS(&table[h], -1, g);
+        if (old == -1) {
+          if (atomicAdd(s_count, 1) >= kMaxLoad) *(volatile int*)s_overflow = 1;
+          break;
+        }
+        if (old == g) break;
+      }
+      h = (h + 1) & (kSlots - 1);
+    }
+  }
+  __syncthreads();
+  return *s_overflow == 0;
+}
+
+template <typename IndT>
+__global__ __launch_bounds__(kBuildThreads) void compact_count_kernel(const IndT* __restrict__ indptr,
+                                                                      const int32_t* __restrict__ gidx, long n_rows,
+                                                                      int32_t* __restrict__ chunk_counts,
+                                                                      uint8_t* __restrict__ chunk_rounds) {
+  __shared__ int table[kSlots];
+  __shared__ int s_count, s_overflow;
+  const long chunk = blockIdx.x;
+  const long r0 = chunk * RG_COMPACT_ROWS;
+  const long r1 = r0 + RG_COMPACT_ROWS < n_rows ? r0 + RG_COMPACT_ROWS : n_rows;
+  const long p0 = (long)indptr[r0], p1 = (long)indptr[r1];
+  int rounds = 1, total = 0;
+  while (true) {
+    total = 0;
+    bool ok = true;
+    for (int r = 0; r < rounds && ok; ++r) {
+      ok = insert_round<IndT>(gidx, p0, p1, rounds, r, table, &s_count, &s_overflow);
+      total += s_count;
+      __syncthreads();
+    }
+    if (ok) break;
+    rounds *= 2;
+    if (rounds > kMaxRounds) { total = 65537; rounds = kMaxRounds; break; }   // not compactable
+  }
+  if (threadIdx.x == 0) {
+    chunk_counts[chunk] = total;
+    chunk_rounds[chunk] = (uint8_t)rounds;
+  }
+}
+
+template <typename IndT>
+__global__ __launch_bounds__(kBuildThreads) void compact_fill_kernel(const IndT* __restrict__ indptr,
+                                                                     const int32_t* __restrict__ gidx, long n_rows,
+                                                                     const int64_t* __restrict__ dict_ptr,
+                                                                     const uint8_t* __restrict__ chunk_rounds,
+                                                                     int32_t* __restrict__ dict,
+                                                                     uint16_t* __restrict__ local_idx) {
+  __shared__ int table[kSlots];
+  __shared__ unsigned short ids[kSlots];
+  __shared__ int part[kBuildThreads];
+  __shared__ int s_count, s_overflow;
+  const long chunk = blockIdx.x;
+  const long r0 = chunk * RG_COMPACT_ROWS;
+  const long r1 = r0 + RG_COMPACT_ROWS < n_rows ? r0 + RG_COMPACT_ROWS : n_rows;
+  const long p0 = (long)indptr[r0], p1 = (long)indptr[r1];
+  const long d0 = dict_ptr[chunk];
+  const int rounds = chunk_rounds[chunk];
+  int base = 0;
+  constexpr int kPer = kSlots / kBuildThreads;   // consecutive slots per thread
+  for (int r = 0; r < rounds; ++r) {
+    insert_round<IndT>(gidx, p0, p1, rounds, r, table, &s_count, &s_overflow);   // cannot overload: counted before
+    // positions of the occupied slots: per-thread count, block exclusive scan, then slot by slot
+    int mine = 0;
+    for (int k = 0; k < kPer; ++k) mine += table[threadIdx.x * kPer + k] != -1;
+    part[threadIdx.x] = mine;
+    __syncthreads();
+    for (int off = 1; off < kBuildThreads; off <<= 1) {
+      const int add = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+      __syncthreads();
+      part[threadIdx.x] += add;
+      __syncthreads();
+    }
+    int pos = base + part[threadIdx.x] - mine;
+    for (int k = 0; k < kPer; ++k) {
+      const int slot = threadIdx.x * kPer + k;
+      const int g = table[slot];
+      if (g != -1) {
+        ids[slot] = (unsigned short)pos;
+        dict[d0 + pos] = g;
+        ++pos;
+      }
+    }
+    __syncthreads();
+    for (long p = p0 + threadIdx.x; p < p1; p += kBuildThreads) {
+      const int g = gidx[p];
+      if (rounds > 1 && (int)(round_hash((unsigned)g) & (unsigned)(rounds - 1)) != r) continue;
+      unsigned h = slot_hash((unsigned)g);
+      while (table[h] != g) h = (h + 1) & (kSlots - 1);
+      local_idx[p] = ids[h];
+    }
+    base += s_count;
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+extern "C" int rg_csr_compact_count(const void* indptr, int32_t indptr_is_i64, const int32_t* gate_idx, int64_t n_rows,
+                                    int32_t* chunk_counts, uint8_t* chunk_rounds, rg_stream_t stream) {
+  RG_REQUIRE(n_rows >= 0, RG_EINVAL, "rg_csr_compact_count: negative size");
+  if (n_rows == 0) return RG_OK;
+  RG_REQUIRE(indptr && chunk_counts && chunk_rounds, RG_EINVAL, "rg_csr_compact_count: null pointer");
+  const long chunks = (n_rows + RG_COMPACT_ROWS - 1) / RG_COMPACT_ROWS;
+  hipStream_t s = (hipStream_t)stream;
+  if (indptr_is_i64)
+    hipLaunchKernelGGL(compact_count_kernel<int64_t>, dim3((unsigned)chunks), dim3(kBuildThreads), 0, s,
+                       static_cast<const int64_t*>(indptr), gate_idx, (long)n_rows, chunk_counts, chunk_rounds);
+  else
+    hipLaunchKernelGGL(compact_count_kernel<int32_t>, dim3((unsigned)chunks), dim3(kBuildThreads), 0, s,
+                       static_cast<const int32_t*>(indptr), gate_idx, (long)n_rows, chunk_counts, chunk_rounds);
+  return rg::check_launch("rg_csr_compact_count");
+}
+
+extern "C" int rg_csr_compact_fill(const void* indptr, int32_t indptr_is_i64, const int32_t* gate_idx, int64_t n_rows,
+                                   const int64_t* dict_ptr, const uint8_t* chunk_rounds, int32_t* dict,
+                                   uint16_t* local_idx, rg_stream_t stream) {
+  RG_REQUIRE(n_rows >= 0, RG_EINVAL, "rg_csr_compact_fill: negative size");
+  if (n_rows == 0) return RG_OK;
+  RG_REQUIRE(indptr && dict_ptr && chunk_rounds, RG_EINVAL, "rg_csr_compact_fill: null pointer");
+  const long chunks = (n_rows + RG_COMPACT_ROWS - 1) / RG_COMPACT_ROWS;
+  hipStream_t s = (hipStream_t)stream;
+  if (indptr_is_i64)
+    hipLaunchKernelGGL(compact_fill_kernel<int64_t>, dim3((unsigned)chunks), dim3(kBuildThreads), 0, s,
+                       static_cast<const int64_t*>(indptr), gate_idx, (long)n_rows, dict_ptr, chunk_rounds, dict, local_idx);
+  else
+    hipLaunchKernelGGL(compact_fill_kernel<int32_t>, dim3((unsigned)chunks), dim3(kBuildThreads), 0, s,
+                       static_cast<const int32_t*>(indptr), gate_idx, (long)n_rows, dict_ptr, chunk_rounds, dict, local_idx);
+  return rg::check_launch("rg_csr_compact_fill");
+}

@@ -164,8 +164,7 @@ class RoiSearch:
         return DeviceCSR(indptr, gate_idx, weights, max_gate)
 
 
-def _build_compact_only(search: "RoiSearch", weighting: str, pairs_per_slab: int = 1_200_000_000,
-                        chunks_per_pass: int = 8192):
+def _build_compact_only(search: "RoiSearch", weighting: str, pairs_per_slab: int = 1_200_000_000):
     """Count -> scan -> per slab of whole grid levels: fill the slab's gate indices into a scratch buffer, derive the
     dictionaries and 16-bit positions of the 256-row chunks it completes, drop the scratch (the rows of a chunk that
     straddles the slab boundary are carried into the next slab).  The int32 index array of the whole grid -- half of
@@ -197,10 +196,7 @@ def _build_compact_only(search: "RoiSearch", weighting: str, pairs_per_slab: int
         n_pairs = int(level_ptr[-1])
         weights = torch.empty(max(n_pairs, 1), dtype=torch.float32, device=dev)[:n_pairs]
         local = torch.empty(max(n_pairs, 1), dtype=torch.int16, device=dev)[:n_pairs]
-        n_chunks = (n_vox + rows - 1) // rows
-        c_counts = torch.zeros(n_chunks, dtype=torch.int64, device=dev)
-        c_pairs = torch.zeros(n_chunks, dtype=torch.int64, device=dev)
-        parts = []
+        count_parts, dict_parts = [], []
         max_gate = -1
         done_row = 0                                              # rows below are compacted; always a chunk boundary
         carry = torch.empty(0, dtype=torch.int32, device=dev)    # gate indices of rows [done_row, first row of the slab)
@@ -225,27 +221,21 @@ def _build_compact_only(search: "RoiSearch", weighting: str, pairs_per_slab: int
             if end_row > done_row:
                 ip = indptr[done_row:end_row + 1]
                 q0, q1 = int(ip[0]), int(ip[-1])                  # q0 == p0 - n_carry
-                c0, c1 = done_row // rows, (end_row + rows - 1) // rows
                 if q1 > q0:
                     max_gate = max(max_gate, int(scratch[:q1 - q0].max().item()))
-                    for s0 in range(c0, c1, chunks_per_pass):     # torch.unique needs ~50 bytes of scratch per pair
-                        s1 = min(c1, s0 + chunks_per_pass)
-                        ip_s = indptr[s0 * rows:min(end_row, s1 * rows) + 1]
-                        a, b = int(ip_s[0]) - q0, int(ip_s[-1]) - q0
-                        if b == a:
-                            continue
-                        part = CompactCSR._slab(ip_s, scratch[a:b], s1 - s0, local[q0 + a:q0 + b], c_counts[s0:s1],
-                                                c_pairs[s0:s1])
-                        if part is None:
-                            return None
-                        parts.append(part)
+                built = CompactCSR._rows(ip, _native.ptr(scratch) - 4 * q0, end_row - done_row, _native.ptr(local))
+                if built is None:
+                    return None
+                count_parts.append(built[0])
+                dict_parts.append(built[1])
                 carry = scratch[q1 - q0:].clone()
                 done_row = end_row
             else:
                 carry = scratch
             del scratch
             iz0 = iz1
-        compact = CompactCSR._finish(local, c_counts, c_pairs, parts)
+        counts_all = torch.cat(count_parts) if count_parts else torch.zeros(0, dtype=torch.int64, device=dev)
+        compact = CompactCSR._finish(indptr, n_vox, local, counts_all, dict_parts)
         if n_pairs <= _INT32_MAX:
             indptr = indptr.to(torch.int32)
     return DeviceCSR(indptr, None, weights, max_gate), compact

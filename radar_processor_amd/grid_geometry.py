@@ -60,64 +60,66 @@ class CompactCSR:
         return sum(int(t.numel()) * t.element_size() for t in (self.local_idx, self.dict_ptr, self.dict))
 
     @classmethod
-    def build(cls, csr: "DeviceCSR", chunks_per_slab: int = 8192) -> Optional["CompactCSR"]:
-        """Derive the compact copy on the device; ``None`` when a chunk references more than 65536 distinct gates
-        (positions are 16 bits; the standard kernel then stays in charge).  Per slab of chunks: key = (chunk, gate)
-        per pair, ``torch.unique`` (sorted) gives the dictionaries and every pair's position."""
+    def build(cls, csr: "DeviceCSR") -> Optional["CompactCSR"]:
+        """Derive the compact copy on the device (``rg_csr_compact_count`` / ``rg_csr_compact_fill``: one workgroup per
+        chunk with an LDS hash set of its gates); ``None`` when a chunk references more than 65536 distinct gates
+        (positions are 16 bits; the standard kernel then stays in charge)."""
         torch = _native.torch_mod()
-        rows = _native.RG_COMPACT_ROWS
-        n_vox, n_pairs = csr.n_vox, csr.n_pairs
-        n_chunks = (n_vox + rows - 1) // rows
         dev = csr.indptr.device
-        local = torch.empty(max(n_pairs, 1), dtype=torch.int16, device=dev)[:n_pairs]
-        counts = torch.zeros(n_chunks, dtype=torch.int64, device=dev)
-        chunk_pairs = torch.zeros(n_chunks, dtype=torch.int64, device=dev)
-        parts = []
-        for c0 in range(0, n_chunks, chunks_per_slab):
-            c1 = min(n_chunks, c0 + chunks_per_slab)
-            r0, r1 = c0 * rows, min(n_vox, c1 * rows)
-            ip = csr.indptr[r0:r1 + 1].to(torch.int64)
-            p0, p1 = int(ip[0]), int(ip[-1])
-            if p1 == p0:
-                continue
-            part = cls._slab(ip, csr.gate_indices[p0:p1], c1 - c0, local[p0:p1], counts[c0:c1], chunk_pairs[c0:c1])
-            if part is None:
-                return None
-            parts.append(part)
-        return cls._finish(local, counts, chunk_pairs, parts)
+        local = torch.empty(max(csr.n_pairs, 1), dtype=torch.int16, device=dev)[:csr.n_pairs]
+        with torch.cuda.device(dev):
+            built = cls._rows(csr.indptr, _native.ptr(csr.gate_indices), csr.n_vox, _native.ptr(local))
+        if built is None:
+            return None
+        counts, dict_ = built
+        return cls._finish(csr.indptr, csr.n_vox, local, counts, [dict_])
 
     @staticmethod
-    def _slab(ip, gate_idx, n_chunks: int, local_out, counts_out, pairs_out):
-        """One slab of whole chunks: ``ip`` = its int64 row pointers (absolute), ``gate_idx`` = the gate indices of
-        its pairs.  Fills the slab's positions / counts and returns its dictionaries, or ``None`` when a chunk holds
-        more than 65536 distinct gates."""
+    def _rows(indptr, gate_idx_ptr: int, n_rows: int, local_ptr: int):
+        """Dictionaries and positions of the chunks of ``n_rows`` rows whose (absolute) row pointers are ``indptr``
+        (a tensor of ``n_rows + 1`` entries, possibly a view into a longer one).  ``gate_idx_ptr`` / ``local_ptr`` are
+        device addresses such that element ``p`` belongs to absolute pair ``p``.  Returns ``(counts int64 [chunks],
+        dict int32)`` with the dictionaries back to back, or ``None`` when a chunk is too rich."""
         torch = _native.torch_mod()
+        lib = _native.load_library()
         rows = _native.RG_COMPACT_ROWS
-        n_rows = int(ip.shape[0]) - 1
-        n_p = int(gate_idx.shape[0])
-        chunk_of_row = torch.arange(n_rows, device=ip.device, dtype=torch.int64) // rows
-        chunk_of_pair = torch.repeat_interleave(chunk_of_row, ip[1:] - ip[:-1], output_size=n_p)
-        key = (chunk_of_pair << 32) | gate_idx.to(torch.int64)
-        uniq, inverse = torch.unique(key, return_inverse=True)
-        del key
-        cnt = torch.bincount(uniq >> 32, minlength=n_chunks)
-        if int(cnt.max()) > 65536:
+        dev = indptr.device
+        n_chunks = (n_rows + rows - 1) // rows
+        if n_chunks == 0:
+            return torch.zeros(0, dtype=torch.int64, device=dev), torch.zeros(0, dtype=torch.int32, device=dev)
+        is_i64 = int(indptr.dtype == torch.int64)
+        stream = _native.stream_ptr()
+        counts = torch.zeros(n_chunks + 1, dtype=torch.int32, device=dev)
+        rounds = torch.empty(n_chunks, dtype=torch.uint8, device=dev)
+        _native.check(lib.rg_csr_compact_count(_native.ptr(indptr), is_i64, gate_idx_ptr, n_rows, _native.ptr(counts),
+                                               _native.ptr(rounds), stream), "rg_csr_compact_count")
+        if int(counts.max()) > 65536:
             return None
-        start = torch.cumsum(cnt, 0) - cnt
-        local_out.copy_((inverse - start[chunk_of_pair]).to(torch.int16))   # bit pattern of the uint16 position
-        counts_out.copy_(cnt)
-        pairs_out.copy_(torch.bincount(chunk_of_pair, minlength=n_chunks))
-        return (uniq & 0xFFFFFFFF).to(torch.int32)
+        dict_ptr = torch.empty(n_chunks + 1, dtype=torch.int64, device=dev)
+        ws_bytes = int(lib.rg_scan_workspace_bytes(n_chunks))
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+        _native.check(lib.rg_scan_counts_i64(_native.ptr(counts), n_chunks, _native.ptr(dict_ptr), _native.ptr(ws), ws_bytes,
+                                             stream), "rg_scan_counts_i64")
+        n_dict = int(dict_ptr[-1])
+        dict_ = torch.empty(max(n_dict, 1), dtype=torch.int32, device=dev)[:n_dict]
+        _native.check(lib.rg_csr_compact_fill(_native.ptr(indptr), is_i64, gate_idx_ptr, n_rows, _native.ptr(dict_ptr),
+                                              _native.ptr(rounds), _native.ptr(dict_), local_ptr, stream),
+                      "rg_csr_compact_fill")
+        return counts[:n_chunks].to(torch.int64), dict_
 
     @classmethod
-    def _finish(cls, local, counts, chunk_pairs, parts) -> "CompactCSR":
+    def _finish(cls, indptr, n_vox: int, local, counts, parts) -> "CompactCSR":
         torch = _native.torch_mod()
+        rows = _native.RG_COMPACT_ROWS
         dev = counts.device
         n_chunks = int(counts.shape[0])
         dict_ptr = torch.zeros(n_chunks + 1, dtype=torch.int64, device=dev)
         dict_ptr[1:] = torch.cumsum(counts, 0)
         dict_ = torch.cat(parts) if parts else torch.zeros(1, dtype=torch.int32, device=dev)[:0]
         # LDS window: the smallest size that leaves at most 0.1 % of the pairs to the per-pair fallback
+        bounds = torch.clamp(torch.arange(n_chunks + 1, device=dev, dtype=torch.int64) * rows, max=n_vox)
+        edges = indptr[bounds].to(torch.int64)
+        chunk_pairs = edges[1:] - edges[:-1]
         window_cap = _native.RG_COMPACT_MAX_WINDOW
         total = max(int(chunk_pairs.sum()), 1)
         for cap in (1024, 2048, 4096, 8192):

@@ -161,7 +161,7 @@ _COMPACT_MAX_USEFUL_WINDOW = 4096   # LDS window (values) beyond which the compa
 
 
 def _use_compact(geometry: GridGeometry, dev) -> bool:
-    """Policy for single-field passes: the compact copy of the CSR costs a one-time conversion (about 0.2 s per
+    """Policy for single-field passes: the compact copy of the CSR costs a one-time conversion (about 15 ms per
     1e9 pairs) and 2.3 bytes per pair of HBM, so it is built the SECOND time a geometry grids a single field, when
     the geometry is large enough to matter and the memory is there; once built it is always used."""
     cached = getattr(geometry, "_compact", None)

@@ -192,6 +192,18 @@ def test_c2_compact_csr_is_bit_identical(c2):
     pos = c.local_idx[pairs].to(torch.int64) & 0xFFFF
     decoded = c.dict[c.dict_ptr[rows // _native.RG_COMPACT_ROWS] + pos]
     assert bool((decoded == csr.gate_indices[pairs]).all())
+    # the dictionaries hold every chunk's distinct gates exactly once (checked against torch.unique on 4096 chunks)
+    rows_per = _native.RG_COMPACT_ROWS
+    c0, c1 = 30000, 34096
+    ipw = ip[c0 * rows_per:c1 * rows_per + 1]
+    chunk_of_pair = torch.repeat_interleave(torch.arange(c0 * rows_per, c1 * rows_per, device=dev) // rows_per,
+                                            ipw[1:] - ipw[:-1])
+    keys = (chunk_of_pair << 32) | csr.gate_indices[int(ipw[0]):int(ipw[-1])].to(torch.int64)
+    want_keys = torch.unique(keys)
+    d0, d1 = int(c.dict_ptr[c0]), int(c.dict_ptr[c1])
+    chunk_of_entry = torch.repeat_interleave(torch.arange(c0, c1, device=dev), c.dict_ptr[c0 + 1:c1 + 1] - c.dict_ptr[c0:c1])
+    got_keys = torch.sort((chunk_of_entry << 32) | c.dict[d0:d1].to(torch.int64)).values
+    assert bool(torch.equal(got_keys, want_keys))
     # grids
     g_c.pack([f], [m]); g_s.pack([f], [m])
     want = torch.empty((1, g_s.n_vox), dtype=torch.float32, device=dev)
