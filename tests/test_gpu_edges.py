@@ -260,3 +260,46 @@ def test_compact_csr_edge_shapes(rg, tmp_path, shape):
             c.window_cap, 256, _native.stream_ptr()), "rg_csr_compact_apply_f32")
         # another tile size regroups the float32 partial sums: equal to rounding, not bit for bit
         np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=2e-6, atol=1e-5)
+
+
+def test_compact_csr_rich_chunks(rg):
+    """Chunks far richer than the radar geometries produce: ~45 000 distinct gates per 256-row chunk force the LDS hash
+    set of the builder through 8-16 rounds and every chunk of the kernel onto the per-pair fallback; a chunk with more
+    than 65 536 distinct gates makes the geometry non-compactable.  Hand-made CSR, compared bit for bit with the
+    standard kernel and decoded back to the original indices."""
+    import torch
+    from radar_processor_amd.gridding import CsrGridder
+    from radar_processor_amd.grid_geometry import CompactCSR, DeviceCSR, GridGeometry
+    dev = torch.device("cuda")
+    gen = torch.Generator(device=dev).manual_seed(5)
+    n_gates, n_rows = 300_000, 1000                      # 4 chunks, the last one partial (232 rows)
+    lengths = torch.randint(150, 260, (n_rows,), device=dev, generator=gen)
+    lengths[17] = 0
+    lengths[300:310] = 0
+    indptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=dev)
+    indptr[1:] = torch.cumsum(lengths, 0)
+    n_pairs = int(indptr[-1])
+    gidx = torch.randint(0, n_gates, (n_pairs,), device=dev, generator=gen, dtype=torch.int32)
+    gidx[:5000] = gidx[0]                                # plus one heavily repeated gate
+    wts = torch.rand(n_pairs, device=dev, generator=gen) + 0.01
+    shape, limits = (1, 1, n_rows), ((0.0, 0.0), (0.0, 0.0), (0.0, 1.0))
+    csr = DeviceCSR(indptr.to(torch.int32), gidx, wts, int(gidx.max()))
+    geom = GridGeometry.from_device(shape, limits, csr, 17000.0)
+    compact = geom.device_compact(dev)
+    assert compact is not None and compact.max_dict > 40000 and compact.window_cap == 8192
+    assert torch.equal(compact.decode(csr), gidx)
+    values = torch.randn(n_gates, device=dev, generator=gen)
+    mask = (torch.rand(n_gates, device=dev, generator=gen) < 0.2).to(torch.uint8)
+    g_c = CsrGridder(geom, n_gates, 1, device=dev)
+    g_c.compact = compact                                # force the copy although its window is past the useful size
+    g_s = CsrGridder(geom, n_gates, 1, device=dev)
+    g_c.pack([values], [mask]); g_s.pack([values], [mask])
+    want = torch.empty((1, n_rows), dtype=torch.float32, device=dev)
+    got = torch.empty_like(want)
+    g_s.apply(want); g_c.apply(got)
+    assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+    # more than 65536 distinct gates in one chunk: not compactable
+    rich = torch.arange(256 * 300, device=dev, dtype=torch.int32)
+    ip2 = torch.arange(0, 256 * 300 + 1, 300, device=dev, dtype=torch.int64)
+    csr2 = DeviceCSR(ip2.to(torch.int32), rich, torch.ones(rich.numel(), device=dev), int(rich.max()))
+    assert CompactCSR.build(csr2) is None
