@@ -28,12 +28,13 @@ class VolumePipeline:
     """
 
     def __init__(self, geometry: GridGeometry, n_gates: int, n_fields: int = 1, cappi_altitude: float = 4000.0,
-                 fill_value: float = np.nan, use_graph: bool = True, device=None):
+                 fill_value: float = np.nan, use_graph: bool = True, device=None, compact: bool = False):
         torch = _native.torch_mod()
         self.lib = _native.load_library()
         self.dev = _native.device() if device is None else device
         self.geometry = geometry
-        self.gridder = CsrGridder(geometry, n_gates, n_fields, device=self.dev)
+        # compact=True: single-field pipelines over a large geometry grid through its compact CSR copy (identical bits)
+        self.gridder = CsrGridder(geometry, n_gates, n_fields, device=self.dev, compact=compact)
         self.n_fields, self.n_gates = int(n_fields), int(n_gates)
         self.fill_value = fill_value
         nz, ny, nx = self.gridder.grid_shape

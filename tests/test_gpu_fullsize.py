@@ -270,3 +270,23 @@ def test_c2_compact_only_layout(c2, tmp_path):
     with pytest.raises(ValueError):
         rg.compute_grid_geometry(vol.gate_x, vol.gate_y, vol.gate_z, cfg["grid_shape"], cfg["grid_limits"],
                                  str(tmp_path), layout="coo")
+
+
+def test_c2_pipeline_graph_with_compact_copy(c2):
+    """VolumePipeline(compact=True): the captured hipGraph (pack -> rg_csr_compact_apply_f32 -> COLMAX/argmax -> CAPPI)
+    replays to the same bits as the standard pipeline."""
+    from radar_processor_amd.pipeline import VolumePipeline
+    torch, geom, dev = c2["torch"], c2["geom"], c2["dev"]
+    f, m = c2["fields"]["DBZH"], c2["masks"]["DBZH"]
+    outs = []
+    for compact in (False, True):
+        pipe = VolumePipeline(geom, f.numel(), 1, compact=compact, device=dev)
+        assert (pipe.gridder.compact is not None) == compact
+        pipe.run([f], [m])
+        res = pipe.run([f], [m])                    # second call replays the graph
+        torch.cuda.synchronize()
+        outs.append([res[k].clone() for k in ("grid", "colmax", "argmax", "cappi")])
+    assert len(outs[0]) == len(outs[1]) and len(outs[0]) > 0
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a,
+                           b.view(torch.int32) if b.dtype == torch.float32 else b)
