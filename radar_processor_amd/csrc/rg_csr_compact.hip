@@ -226,8 +226,8 @@ extern "C" int rg_csr_compact_apply_f32(const void* indptr, int32_t indptr_is_i6
 // overload the table are processed in R = 2, 4, ... 32 rounds, round r taking the gates of one residue class of a
 // second hash, so any chunk up to 65536 distinct gates is handled with 32 KiB of LDS.
 //   count pass: distinct gates per chunk (and the rounds it needed)   -> rg_scan_counts_i64 gives dict_ptr
-//   fill pass : same rounds; occupied slots get consecutive positions (block prefix sum), the dictionary is written,
-//               and a second sweep over the round's pairs looks every gate up and stores its 16-bit position.
+//   fill pass : same rounds; the lane that claims a slot gives the gate the next position and writes the dictionary
+//               entry, a second sweep over the round's pairs looks every gate up and stores its 16-bit position.
 // Positions depend on the insertion order (not reproducible run to run); the gridding result does not.
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
@@ -241,9 +241,13 @@ __device__ __forceinline__ unsigned slot_hash(unsigned g) { return (g * 26544357
 __device__ __forceinline__ unsigned round_hash(unsigned g) { return (g * 0x85EBCA6Bu) >> 27; }     // 5 bits
 
 // Inserts the gates of residue class `r` (of `rounds`) among pairs [p0, p1).  Returns false when the table overloads.
+// With `ids`, the lane that claims a slot also gives the gate its position (base + order of arrival) and writes the
+// dictionary entry: positions then follow the order in which the chunk's pairs first mention a gate, so the 64
+// consecutive pairs of one gather mostly hold neighbouring positions (fewer LDS bank conflicts than any fixed order).
 template <typename IndT>
 __device__ bool insert_round(const int32_t* __restrict__ gidx, long p0, long p1, int rounds, int r, int* table,
-                             int* s_count, int* s_overflow) {
+                             int* s_count, int* s_overflow, unsigned short* ids = nullptr, int base = 0,
+                             int32_t* __restrict__ dict_out = nullptr) {
   for (int i = threadIdx.x; i < kSlots; i += kBuildThreads) table[i] = -1;
   if (threadIdx.x == 0) { *s_count = 0; *s_overflow = 0; }
   __syncthreads();
@@ -258,7 +262,12 @@ __device__ bool insert_round(const int32_t* __restrict__ gidx, long p0, long p1,
         if (*(volatile int*)s_overflow) break;
         const int old = atomicCAS(&table[h], -1, g);
         if (old == -1) {
-          if (atomicAdd(s_count, 1) >= kMaxLoad) *(volatile int*)s_overflow = 1;
+          const int order = atomicAdd(s_count, 1);
+          if (order >= kMaxLoad) *(volatile int*)s_overflow = 1;
+          if (ids) {
+            ids[h] = (unsigned short)(base + order);
+            dict_out[base + order] = g;
+          }
           break;
         }
         if (old == g) break;
@@ -309,7 +318,6 @@ __global__ __launch_bounds__(kBuildThreads) void compact_fill_kernel(const IndT*
                                                                      uint16_t* __restrict__ local_idx) {
   __shared__ int table[kSlots];
   __shared__ unsigned short ids[kSlots];
-  __shared__ int part[kBuildThreads];
   __shared__ int s_count, s_overflow;
   const long chunk = blockIdx.x;
   const long r0 = chunk * RG_COMPACT_ROWS;
@@ -318,31 +326,9 @@ __global__ __launch_bounds__(kBuildThreads) void compact_fill_kernel(const IndT*
   const long d0 = dict_ptr[chunk];
   const int rounds = chunk_rounds[chunk];
   int base = 0;
-  constexpr int kPer = kSlots / kBuildThreads;   // consecutive slots per thread
   for (int r = 0; r < rounds; ++r) {
-    insert_round<IndT>(gidx, p0, p1, rounds, r, table, &s_count, &s_overflow);   // cannot overload: counted before
-    // positions of the occupied slots: per-thread count, block exclusive scan, then slot by slot
-    int mine = 0;
-    for (int k = 0; k < kPer; ++k) mine += table[threadIdx.x * kPer + k] != -1;
-    part[threadIdx.x] = mine;
-    __syncthreads();
-    for (int off = 1; off < kBuildThreads; off <<= 1) {
-      const int add = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
-      __syncthreads();
-      part[threadIdx.x] += add;
-      __syncthreads();
-    }
-    int pos = base + part[threadIdx.x] - mine;
-    for (int k = 0; k < kPer; ++k) {
-      const int slot = threadIdx.x * kPer + k;
-      const int g = table[slot];
-      if (g != -1) {
-        ids[slot] = (unsigned short)pos;
-        dict[d0 + pos] = g;
-        ++pos;
-      }
-    }
-    __syncthreads();
+    // cannot overload: the count pass sized the rounds
+    insert_round<IndT>(gidx, p0, p1, rounds, r, table, &s_count, &s_overflow, ids, base, dict + d0);
     for (long p = p0 + threadIdx.x; p < p1; p += kBuildThreads) {
       const int g = gidx[p];
       if (rounds > 1 && (int)(round_hash((unsigned)g) & (unsigned)(rounds - 1)) != r) continue;
