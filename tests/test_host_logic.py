@@ -249,6 +249,19 @@ class TestNativeLibrary:
             rg.column_max(np.zeros((4, 5, 6), dtype=np.float32))
         with pytest.raises(rg.NativeUnavailable):
             rg.constant_altitude_ppi(np.zeros((4, 5, 6), dtype=np.float32), geometry, 1500.0)
+        # the raster stage and the 2-D filters have no CPU path either
+        plane = np.ma.masked_invalid(np.linspace(-30, 60, 30, dtype=np.float32).reshape(5, 6))
+        with pytest.raises(rg.NativeUnavailable):
+            rg.collapse_field_3d_to_2d(np.zeros((4, 5, 6), dtype=np.float32), "colmax")
+        with pytest.raises(rg.NativeUnavailable):
+            rg.apply_filter_masks(plane, [type("F", (), {"field": "DBZH", "min": 0.0, "max": None})()], [], "DBZH", {"qc": {}})
+        with pytest.raises(rg.NativeUnavailable):
+            rg.apply_colormap_to_array(plane.filled(np.nan), np.array([[0, 0, 0], [1, 1, 1]], dtype=float), 0.0, 1.0)
+        with pytest.raises(rg.NativeUnavailable):
+            rg.GridFilter().apply_below(plane.filled(np.nan), 15.0)
+        with pytest.raises(rg.NativeUnavailable):
+            rg.compute_grid_geometry(np.zeros(4, np.float32), np.zeros(4, np.float32), np.zeros(4, np.float32), (1, 2, 2),
+                                     ((0.0, 0.0), (0.0, 1.0), (0.0, 1.0)), ".", layout="compact")
 
     def test_product_package_never_imports_the_oracle(self):
         pkg_dir = os.path.dirname(rg.__file__)
