@@ -105,7 +105,7 @@ int rg_csr_apply_f32(const void* indptr, int32_t indptr_is_i64, const int32_t* g
                      int64_t n_vox, int64_t n_pairs,
                      const float* packed, int32_t n_fields, int32_t stride, int64_t n_gates,
                      float fill_value, float* out, rg_stream_t stream);
-/* diagnostic: same kernel family with a tuning variant (tile size / cache policy) selected explicitly;
+/* diagnostic: same kernel with a tuning variant (tile size, waves per workgroup, pipeline depth, placement) selected explicitly;
  * variant 0 is what rg_csr_apply_f32 runs.  Used only by tools/tune_k1.py for A/B timing in one process. */
 int rg_csr_apply_f32_ex(const void* indptr, int32_t indptr_is_i64, const int32_t* gate_idx, const float* weights,
                         int64_t n_vox, int64_t n_pairs,

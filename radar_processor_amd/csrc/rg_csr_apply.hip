@@ -15,17 +15,12 @@
 //                  gates, i.e. few cache lines per instruction;
 //   stream(t+2)    coalesced dword loads of gate_idx and weights (256 contiguous bytes per wave-instruction,
 //                  consecutive instructions consecutive) -- in flight for a whole iteration;
-//   row phase(t)   LDS is the transposition buffer from pair order to row order.  Two implementations:
-//                  csr_apply_dyn_kernel (DEFAULT): the rows that touch the tile share the 64 lanes dynamically,
-//                  per-row sums live in LDS (see the comment at that kernel);
-//                  csr_apply_kernel (tuning variant): a static layout, LPR = max(4, stride) lanes per row and
-//                  64/LPR rows per pass, per-pass accumulators in registers;
+//   row phase(t)   LDS is the transposition buffer from pair order to row order: the rows that touch the tile share
+//                  the 64 lanes dynamically, per-row sums live in LDS (see the comment at the kernel);
 //   epilogue       combine, divide in float64, coalesced store of out[f][row].
 //
 // Empty rows cost nothing, long rows only lengthen their own lanes' loop; no workgroup barrier, no atomics, no
 // inter-wave communication, so results are bit-reproducible run to run.
-#include <type_traits>
-
 #include "rg_common.hpp"
 
 // 8- and 16-byte buffer loads by intrinsic name: this compiler's __builtin_amdgcn_raw_buffer_load_b64 / _b128 return
@@ -68,184 +63,13 @@ __device__ __forceinline__ unsigned place_block(unsigned bid, unsigned nblk) {
 
 // tuning / diagnostic flags (template parameter FLAGS)
 constexpr int kNoGather = 1;     // timing-only ablation: skip the gather (results are wrong by construction)
-constexpr int kNoRows = 2;       // timing-only ablation: skip the row phase
-constexpr int kNonTemporal = 4;  // stream the CSR with the nt cache policy
-constexpr int kAcc32 = 8;        // per-row accumulators in float32 instead of float64 (fewer VGPRs)
-constexpr int kFlatOrder = 16;   // gather at the top of the iteration (no gather-ahead pipelining)
 constexpr int kWpb1 = 256, kWpb2 = 512, kWpb8 = 768;  // dyn kernel only: waves per workgroup (default 4)
 constexpr int kStages3 = 1024;   // dyn kernel only: three CSR tiles in flight per wavefront instead of two
 constexpr int wpb_of(int flags) { return (flags & 768) == 256 ? 1 : (flags & 768) == 512 ? 2 : (flags & 768) == 768 ? 8 : 4; }
 
 using f32x2 = float __attribute__((ext_vector_type(2)));
 
-template <bool NT, typename T>
-__device__ __forceinline__ T stream_load(const T* p) {
-  if constexpr (NT) return __builtin_nontemporal_load(p);
-  else return *p;
-}
-
-template <typename IndT, int NF, int STRIDE, int TILE, int XCD, int FLAGS>
-__global__ __launch_bounds__(rg::kBlock) void csr_apply_kernel(
-    const IndT* __restrict__ indptr, const int32_t* __restrict__ gidx, const float* __restrict__ wts,
-    long n_vox, long n_pairs, const float* __restrict__ packed, unsigned last_gate, float fill,
-    float* __restrict__ out) {
-  static_assert(TILE % 64 == 0, "a wave handles 64 pairs per step");
-  constexpr int IT = TILE / 64;
-  constexpr bool NT = (FLAGS & kNonTemporal) != 0;
-  using acc_t = typename std::conditional<(FLAGS & kAcc32) != 0, float, double>::type;
-  __shared__ f32x2 tile_all[rg::kBlock / rg::kWave][TILE * STRIDE];
-  const int lane = threadIdx.x & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: chunk bounds live in SGPRs
-  f32x2* tile = tile_all[wv];
-
-  const unsigned blk = place_block<XCD>(blockIdx.x, gridDim.x);
-  const long r0 = ((long)blk * (rg::kBlock / rg::kWave) + wv) * 64;
-  if (r0 >= n_vox) return;  // wave-uniform
-  const long row = r0 + lane;
-  const long seg_b = (long)indptr[r0];
-  const long seg_e = (long)indptr[r0 + 64 < n_vox ? r0 + 64 : n_vox];
-  const int span = (int)(seg_e - seg_b);  // a 64-row chunk never holds 2^31 pairs
-  // row bounds as offsets into the chunk's pair range; lane l <-> row r0 + l
-  const int rs_o = (int)((long)indptr[row < n_vox ? row : n_vox] - seg_b);
-  const int re_o = (int)((long)indptr[row + 1 < n_vox ? row + 1 : n_vox] - seg_b);
-  // row-phase layout: LPR lanes per row = STRIDE field slots x SUB sub-lanes; RPP rows per pass; LPR passes
-  constexpr int LPR = STRIDE > 4 ? STRIDE : 4;
-  constexpr int SUB = LPR / STRIDE;
-  constexpr int RPP = 64 / LPR;
-  constexpr int NPASS = LPR;
-  const int rin = lane % LPR;      // position inside the row's lane group
-  const int fslot = rin % STRIDE;  // field slot this lane sums
-  const int sub = rin / STRIDE;    // which of the SUB interleaved element streams
-  const int rlane = lane / LPR;    // row of the pass this lane serves
-  int ps[NPASS], pe[NPASS];        // pair span of each pass's RPP rows (wave-uniform)
-#pragma unroll
-  for (int p = 0; p < NPASS; ++p) {
-    ps[p] = __builtin_amdgcn_readlane(rs_o, RPP * p);
-    pe[p] = __builtin_amdgcn_readlane(re_o, RPP * p + RPP - 1);
-  }
-  acc_t acc_p[NPASS], acc_w[NPASS];
-#pragma unroll
-  for (int p = 0; p < NPASS; ++p) { acc_p[p] = 0; acc_w[p] = 0; }
-
-  if (span > 0) {
-    // Wave-uniform bases + 32-bit lane offsets: one VGPR per load address.  Slots past the end of the arrays
-    // are clamped (computed but never read back by the row phase).
-    const int32_t* __restrict__ gi = gidx + seg_b;
-    const float* __restrict__ wi = wts + seg_b;
-    const long tail = n_pairs - 1 - seg_b;
-    const int kmax = tail < 0x3FFFFFFF ? (int)tail : 0x3FFFFFFF;
-    int ci[IT];
-    float cw[IT];
-    float w_n[IT];
-    float val_n[IT][STRIDE];
-
-    auto stream = [&](int t) {
-#pragma unroll
-      for (int it = 0; it < IT; ++it) {
-        const int k = min(t + it * 64 + lane, kmax);
-        ci[it] = stream_load<NT>(gi + k);
-        cw[it] = stream_load<NT>(wi + k);
-      }
-    };
-    auto gather = [&]() {
-#pragma unroll
-      for (int it = 0; it < IT; ++it) {
-        w_n[it] = cw[it];
-        if constexpr ((FLAGS & kNoGather) != 0) {
-#pragma unroll
-          for (int f = 0; f < STRIDE; ++f) val_n[it][f] = rg::bits_f32((unsigned)ci[it] & 0x3FFFFFFFu);
-        } else {
-          load_packed<STRIDE>(packed, min((unsigned)ci[it], last_gate), val_n[it]);  // clamp: never fault
-        }
-      }
-    };
-
-    stream(0);
-    if constexpr ((FLAGS & kFlatOrder) == 0) {
-      gather();
-      if (TILE < span) stream(TILE);
-    }
-    for (int t = 0; t < span; t += TILE) {
-      if constexpr ((FLAGS & kFlatOrder) != 0) {
-        gather();
-        if (t + TILE < span) stream(t + TILE);
-      }
-      // ---- products of tile t -> LDS ---------------------------------------------------------------
-#pragma unroll
-      for (int it = 0; it < IT; ++it) {
-#pragma unroll
-        for (int f = 0; f < STRIDE; ++f) {   // padding slots hold the sentinel -> (0, 0)
-          const bool ok = f < NF && rg::f32_bits(val_n[it][f]) != RG_EXCLUDED_BITS;
-          f32x2 e;
-          e.x = ok ? w_n[it] * val_n[it][f] : 0.0f;
-          e.y = ok ? w_n[it] : 0.0f;
-          tile[(it * 64 + lane) * STRIDE + f] = e;
-        }
-      }
-      if constexpr ((FLAGS & kFlatOrder) == 0) {
-        // ---- gather for tile t+1, CSR stream for tile t+2: both in flight during the row phase ---------
-        if (t + TILE < span) {
-          gather();
-          if (t + 2 * TILE < span) stream(t + 2 * TILE);
-        }
-      }
-      // LDS traffic of one wave executes in order; the fences only pin the compiler.
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-      // ---- row phase: LPR lanes per row, RPP rows per pass ---------------------------------------------
-#pragma unroll
-      for (int p = 0; p < NPASS; ++p) {
-        if (((FLAGS & kNoRows) != 0) ? (p == 0 && t == 0) : (ps[p] < t + TILE && pe[p] > t)) {  // wave-uniform
-          const int qs = __shfl(rs_o, RPP * p + rlane, 64);
-          const int qe = __shfl(re_o, RPP * p + rlane, 64);
-          const int a = (qs > t ? qs : t) - t;
-          const int b = (qe < t + TILE ? qe : t + TILE) - t;
-          f32x2 part0 = (f32x2)(0.0f), part1 = (f32x2)(0.0f);
-          int j = a + sub;
-          for (; j + SUB < b; j += 2 * SUB) {  // two elements per trip, two independent partial sums
-            part0 += tile[j * STRIDE + fslot];
-            part1 += tile[(j + SUB) * STRIDE + fslot];
-          }
-          if (j < b) part0 += tile[j * STRIDE + fslot];
-          const f32x2 sum = part0 + part1;
-          acc_p[p] += (acc_t)sum.x;
-          acc_w[p] += (acc_t)sum.y;
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-  }
-
-  // ---- epilogue: combine the SUB sub-lanes of every (row, field) in float64, divide, store ----------------
-  float res = fill;
-#pragma unroll
-  for (int p = 0; p < NPASS; ++p) {
-    double sp = (double)acc_p[p], sw = (double)acc_w[p];
-#pragma unroll
-    for (int m = STRIDE; m < LPR; m <<= 1) {  // sub-lanes of one field slot are STRIDE lanes apart
-      sp += __shfl_xor(sp, m, 64);
-      sw += __shfl_xor(sw, m, 64);
-    }
-    const float r = sw > 0.0 ? (float)(sp / sw) : fill;
-    if constexpr (STRIDE == 1) {
-      // one field: row RPP*p + k is held by lane LPR*k; move it to lane == row for one coalesced store
-      const float moved = __shfl(r, LPR * (lane & (RPP - 1)), 64);
-      if ((lane / RPP) == p) res = moved;
-    } else {
-      const long orow = r0 + RPP * p + rlane;
-      if (sub == 0 && fslot < NF && orow < n_vox) out[(size_t)fslot * n_vox + orow] = r;
-    }
-  }
-  if constexpr (STRIDE == 1) {
-    if (row < n_vox) out[row] = res;
-  }
-}
-
-// DEFAULT kernel: same stream / gather / product phases as csr_apply_kernel, with
+// The kernel: the phases above, with
 //   * a DYNAMIC row phase: per tile the rows that actually touch it (a contiguous range, found with one ballot) share
 //     the 64 lanes -- L = the largest power of two <= 64 / rows (at least `stride`) lanes per row, split into stride
 //     field slots x L/stride interleaved element streams -- and the per-row sums live in a small LDS array instead of
@@ -449,66 +273,39 @@ int launch_dyn(const void* indptr, const int32_t* gidx, const float* wts, long n
   return rg::check_launch("rg_csr_apply_f32");
 }
 
-template <typename IndT, int NF, int STRIDE, int TILE, int XCD, int FLAGS>
-int launch(const void* indptr, const int32_t* gidx, const float* wts, long n_vox, long n_pairs, const float* packed,
-           long n_gates, float fill, float* out, hipStream_t s) {
-  const long chunks = (n_vox + 63) / 64;
-  const long blocks = (chunks + 3) / 4;
-  hipLaunchKernelGGL((csr_apply_kernel<IndT, NF, STRIDE, TILE, XCD, FLAGS>), dim3((unsigned)blocks), dim3(rg::kBlock), 0,
-                     s, static_cast<const IndT*>(indptr), gidx, wts, n_vox, n_pairs, packed, (unsigned)(n_gates - 1),
-                     fill, out);
-  return rg::check_launch("rg_csr_apply_f32");
-}
-
 template <typename IndT>
 int dispatch(int nf, int variant, const void* indptr, const int32_t* gidx, const float* wts, long n_vox, long n_pairs,
              const float* packed, long n_gates, float fill, float* out, hipStream_t s) {
-#define RG_K1(NF_, ST_, TILE_, XCD_, FLAGS_) \
-  launch<IndT, NF_, ST_, TILE_, XCD_, FLAGS_>(indptr, gidx, wts, n_vox, n_pairs, packed, n_gates, fill, out, s)
 #define RG_KD(NF_, ST_, TILE_, XCD_, FLAGS_) \
   launch_dyn<IndT, NF_, ST_, TILE_, XCD_, FLAGS_>(indptr, gidx, wts, n_vox, n_pairs, packed, n_gates, fill, out, s)
-  if (nf == 1) {  // tuning variants (tools/tune_k1.py) exist for the single-field kernel only
+  if (nf == 1) {  // tuning variants (tools/tune_k1.py) exist for the single-field kernel only; 0 = what ships
     switch (variant) {
-      case 1: return RG_K1(1, 1, 512, kXcdNone, kAcc32);
-      case 2: return RG_K1(1, 1, 512, kXcdGroup, kAcc32);
-      case 3: return RG_K1(1, 1, 512, kXcdGroup, 0);
-      case 4: return RG_K1(1, 1, 256, kXcdNone, kAcc32);
-      case 5: return RG_K1(1, 1, 512, kXcdNone, kFlatOrder);   // no gather-ahead pipelining
-      case 6: return RG_K1(1, 1, 512, kXcdNone, kNonTemporal);
-      case 7: return RG_K1(1, 1, 384, kXcdNone, 0);
-      case 8: return RG_K1(1, 1, 512, kXcdSlab, 0);
+      case 8: return RG_KD(1, 1, 512, kXcdSlab, 0);       // XCD placement
+      case 16: return RG_KD(1, 1, 512, kXcdGroup, 0);
+      case 18: return RG_KD(1, 1, 256, kXcdNone, 0);      // tile size
+      case 23: return RG_KD(1, 1, 448, kXcdNone, 0);
       case 9: return RG_KD(1, 1, 512, kXcdNone, 0);
-      case 19: return RG_KD(1, 1, 512, kXcdNone, kWpb1);
+      case 17: return RG_KD(1, 1, 640, kXcdNone, 0);
+      case 19: return RG_KD(1, 1, 512, kXcdNone, kWpb1);  // waves per workgroup
       case 20: return RG_KD(1, 1, 512, kXcdNone, kWpb2);
       case 21: return RG_KD(1, 1, 512, kXcdNone, kWpb8);
-      case 16: return RG_KD(1, 1, 512, kXcdGroup, 0);
-      case 28: return RG_KD(1, 1, 512, kXcdNone, kNoGather);            // timing-only ablation of the default kernel
-      case 22: return RG_KD(1, 1, 512, kXcdNone, kStages3);
-      case 23: return RG_KD(1, 1, 448, kXcdNone, 0);
+      case 22: return RG_KD(1, 1, 512, kXcdNone, kStages3);   // three CSR tiles in flight
       case 24: return RG_KD(1, 1, 384, kXcdNone, kStages3);
       case 25: return RG_KD(1, 1, 256, kXcdNone, kStages3);
-      case 26: return RG_KD(1, 1, 320, kXcdNone, kStages3);
-      case 27: return RG_KD(1, 1, 384, kXcdNone, kStages3 | kWpb2);
-      case 17: return RG_KD(1, 1, 640, kXcdNone, 0);
-      case 18: return RG_KD(1, 1, 256, kXcdNone, 0);
-      case 11: return RG_K1(1, 1, 512, kXcdNone, kNoGather);   // timing-only ablations
-      case 12: return RG_K1(1, 1, 512, kXcdNone, kNoRows);
-      case 13: return RG_K1(1, 1, 512, kXcdNone, kNoGather | kNoRows);
-      case 14: return RG_K1(1, 1, 512, kXcdNone, 0);           // static 4-lanes-per-row row phase
+      case 28: return RG_KD(1, 1, 512, kXcdNone, kNoGather);  // timing-only ablation: no field gather
       default: return RG_KD(1, 1, 384, kXcdNone, 0);   // 384-pair tiles: same speed as 512 or slightly better, 72 VGPRs
     }
   }
   switch (nf) {
-    case 2: return variant == 1 ? RG_K1(2, 2, 512, kXcdNone, 0) : RG_KD(2, 2, 512, kXcdNone, 0);
-    case 3: return variant == 1 ? RG_K1(3, 4, 256, kXcdNone, kAcc32) : RG_KD(3, 4, 256, kXcdNone, 0);
-    case 4: return variant == 1 ? RG_K1(4, 4, 256, kXcdNone, kAcc32) : RG_KD(4, 4, 256, kXcdNone, 0);
+    case 2: return RG_KD(2, 2, 512, kXcdNone, 0);
+    case 3: return RG_KD(3, 4, 256, kXcdNone, 0);
+    case 4: return RG_KD(4, 4, 256, kXcdNone, 0);
     case 5: return RG_KD(5, 8, 128, kXcdNone, 0);
     case 6: return RG_KD(6, 8, 128, kXcdNone, 0);
     case 7: return RG_KD(7, 8, 128, kXcdNone, 0);
-    default: return variant == 1 ? RG_K1(8, 8, 128, kXcdNone, kAcc32) : RG_KD(8, 8, 128, kXcdNone, 0);
+    default: return RG_KD(8, 8, 128, kXcdNone, 0);
   }
 #undef RG_KD
-#undef RG_K1
 }
 
 inline int stride_for(int nf) { return nf == 1 ? 1 : nf == 2 ? 2 : nf <= 4 ? 4 : 8; }

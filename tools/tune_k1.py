@@ -2,7 +2,7 @@
 """A/B timing of rg_csr_apply_f32 tuning variants in ONE process, interleaved rounds (cdna_hip_programming.md
 §5.4 rule 24).  Diagnostic tool, not part of the product path.
 
-    python tools/tune_k1.py [--config C2] [--rounds 7] [--variants 0 1 2 3 4]
+    python tools/tune_k1.py [--config C2] [--rounds 7] [--variants 0 9 18 20 22 28]   (see dispatch() in rg_csr_apply.hip)
 """
 import argparse
 import os
@@ -20,7 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="C2")
     ap.add_argument("--rounds", type=int, default=7)
-    ap.add_argument("--variants", type=int, nargs="*", default=[0, 1, 2, 3, 4])
+    ap.add_argument("--variants", type=int, nargs="*", default=[0, 9, 18, 20, 22, 28])
     args = ap.parse_args()
     import torch
     import radar_processor_amd as rg
