@@ -143,6 +143,11 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)      # RCCL over xGMI
         else:
             dist.init_process_group(backend="gloo")
+    if local_rank == 0:
+        from radar_processor_amd.build import ensure_built
+        ensure_built(verbose=rank == 0)          # bare checkout: compile the git-ignored library once per node
+    if world > 1:
+        dist.barrier()
     rg.load_library()
 
     cfg = synthetic.CONFIGS[args.config]

@@ -23,6 +23,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: longer CPU-side oracle checks")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _library_present(request):
+    """GPU runs from a bare checkout: the shared library is git-ignored, so compile it once if it is missing
+    (hipcc is part of the image).  CPU-only runs build it too -- the C-ABI symbol check needs it."""
+    try:
+        from radar_processor_amd.build import ensure_built
+        ensure_built(verbose=False)
+    except Exception as exc:      # no hipcc: the tests that need the library report it themselves
+        print(f"[conftest] could not build libradargrid_hip.so: {exc}")
+
+
 def load_golden(name):
     """Load one fixture: returns (meta dict, {array name: ndarray})."""
     path = os.path.join(GOLDEN, name if name.endswith(".npz") else name + ".npz")
