@@ -1,18 +1,26 @@
 #!/usr/bin/env python3
 """Benchmark of the radar_grid hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config METRIC|C2|C4] [--fields F] [--mode csr|fused]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config METRIC|C2|C4|C5] [--fields F] [--mode csr|fused]
 
-One *step* = one pass of the per-volume hot path over one synthetic volume per GPU, inputs resident in HBM:
-mask fold + field interleave (rg_pack_fields_f32) -> gridding (rg_csr_apply_f32, the dominant kernel) ->
-COLMAX+argmax (rg_column_reduce_f32) -> CAPPI@4000 m (rg_cappi_lerp_f32).  The geometry (CSR) is built once
-on the GPU before the timed region -- that is how the reference uses it too (once per scan strategy,
+One *step* = one pass of the per-volume hot path over one batch of synthetic input per GPU, inputs resident in HBM:
+mask fold + field interleave (rg_pack_fields_f32) -> gridding (rg_csr_compact_apply_f32 / rg_csr_apply_f32, the
+dominant kernel) -> COLMAX+argmax (rg_column_reduce_f32) -> CAPPI@4000 m (rg_cappi_lerp_f32).  The geometry (CSR) is
+built once on the GPU before the timed region -- that is how the reference uses it too (once per scan strategy,
 SURVEY.md §3.1).
 
-Default workload (N=1): the configuration BASELINE.json's metric is quoted on -- the 12-elevation
-360x1000-gate volume onto the 40x2000x2000 grid, one field (DBZH).  For N>1 (launched by
-torch.distributed.run, one rank per GPU) every rank grids its own volume: independent volumes shard with no
-data-path collective (weak scaling); RCCL is used only for the barrier / max-over-ranks of the timing.
+Default workload (N=1): the configuration BASELINE.json's metric is quoted on -- the 12-elevation 360x1000-gate
+volume onto the 40x2000x2000 grid, one field (DBZH), one volume per GPU per step.
+
+``--config C5`` is BASELINE config 5: a batch of ``8 x N`` seeded volumes (volume b -> rank b mod N, seed b; 64 volumes
+on 8 GPUs) sharing one geometry, driven through ``batch.VolumeBatch`` exactly as a user would; a step is one pass over
+this rank's 8 volumes.  Independent volumes shard with NO data-path collective (weak scaling); RCCL is used only for
+the barrier / max-over-ranks of the timing.
+
+Launching: ``python bench.py --gpus N`` starts its own N ranks (fresh child processes, one per GPU, created BEFORE
+anything touches the GPU; rank 0's JSON line is passed through) unless it already runs under a launcher such as
+``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`` (RANK / WORLD_SIZE in the environment), in
+which case WORLD_SIZE must equal ``--gpus``.
 
 Rank 0 prints ONE JSON line on stdout; progress goes to stderr.
 """
@@ -21,6 +29,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -37,38 +47,132 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="METRIC", help="METRIC (default), C2, C4 -- see radar_processor_amd.synthetic.CONFIGS")
+    ap.add_argument("--config", default="METRIC",
+                    help="METRIC (default), C2, C4 -- see radar_processor_amd.synthetic.CONFIGS -- or C5 (batch of 8 "
+                         "volumes per GPU through batch.VolumeBatch)")
     ap.add_argument("--fields", type=int, default=1, help="fields gridded per volume in one fused CSR pass (1..3)")
-    ap.add_argument("--volumes-per-gpu", type=int, default=1, help="volumes fused into each step on every GPU")
+    ap.add_argument("--volumes-per-gpu", type=int, default=None,
+                    help="volumes per GPU per step (default 1; C5: 8)")
+    ap.add_argument("--c5-grid", default="METRIC", choices=("METRIC", "C2"),
+                    help="C5: grid the batch is gridded onto (METRIC = 40x2000x2000, the metric's grid)")
     ap.add_argument("--mode", choices=("csr", "fused"), default="csr",
-                    help="csr = precomputed geometry + rg_csr_apply_f32 (K1); fused = rg_roi_grid_f32 (K2, no CSR)")
+                    help="csr = precomputed geometry + CSR kernels (K1 / K1c); fused = rg_roi_grid_f32 (K2, no CSR)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-compact", action="store_true",
-                    help="csr mode, single field-volume: run the standard 8-byte-per-pair kernel instead of the "
-                         "compact device copy of the CSR (rg_csr_compact_apply_f32, identical results)")
+                    help="csr mode: run the standard 8-byte-per-pair kernel instead of the compact device copy of the "
+                         "CSR (identical results)")
     ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"),
                     help="process-group backend for N>1 (nccl = RCCL; gloo only for rehearsing ranks on one GPU)")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal: every rank uses cuda:0 (needs --dist-backend gloo; RCCL refuses a shared GPU)")
     ap.add_argument("--cpu-sample-pairs", type=float, default=1.5e9, help="upper bound on CSR pairs in the CPU sample")
-    return ap.parse_args()
+    ap.add_argument("--cpu-workers", type=int, default=0, help="processes of the all-core CPU leg (0 = usable cores)")
+    return ap.parse_args(argv)
 
 
-def cpu_baseline(geom, vol, field_name, n_vox_total, max_pairs):
-    """Reference CPU path (NumPy, single thread -- what radar_grid/interpolate.py does) on a bounded sample:
-    whole y-rows around the centre of the grid, CSR rows copied from the GPU-built geometry."""
+# ---------------------------------------------------------------------------------------------------------------
+# launching N ranks from a plain `python bench.py --gpus N`
+# ---------------------------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(args) -> int:
+    """Start ``args.gpus`` fresh child processes, one per GPU, and pass rank 0's stdout through.  Nothing in THIS
+    process touches the GPU (no HIP call, no exec after one): the library is compiled if missing (hipcc, CPU only),
+    the device count is read with ``torch.cuda.device_count()`` (which does not initialise the runtime on this
+    image), then the children are started with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set."""
+    from radar_processor_amd.build import ensure_built
+    ensure_built(verbose=True)
+    n = args.gpus
+    if not args.share_device:
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            log(f"--gpus {n} but only {have} GPU(s) are visible; refusing to label a smaller run as n_gpus={n}")
+            return 2
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "2")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    if any(codes):
+        log(f"rank exit codes: {codes}")
+        return 1
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle = NumPy restatement of radar_grid/interpolate.py:69-104), timed on the host cores
+# ---------------------------------------------------------------------------------------------------------------
+def _cpu_worker(job):
+    """All-core leg: one process, one contiguous block of (z,y) rows of the sample, arrays memory-mapped from the
+    files rank 0 wrote.  Runs in a fresh interpreter (multiprocessing 'spawn'), never touches the GPU."""
+    path, r_lo, r_hi, nx = job
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    if REPO not in sys.path:
+        sys.path.insert(0, REPO)
+    from oracle import radar_grid_oracle as oracle
+    indptr = np.load(os.path.join(path, "indptr.npy"), mmap_mode="r")
+    gidx = np.load(os.path.join(path, "gidx.npy"), mmap_mode="r")
+    wts = np.load(os.path.join(path, "wts.npy"), mmap_mode="r")
+    data = np.load(os.path.join(path, "data.npy"))
+    mask = np.load(os.path.join(path, "mask.npy"))
+    ip = np.asarray(indptr[r_lo * nx:r_hi * nx + 1])
+    p0, p1 = int(ip[0]), int(ip[-1])
+    g = np.asarray(gidx[p0:p1])
+    w = np.asarray(wts[p0:p1])
+    t0 = time.perf_counter()
+    out = oracle.csr_apply(ip - p0, g, w, data, mask, (1, r_hi - r_lo, nx))
+    dt = time.perf_counter() - t0
+    return p1 - p0, dt, float(np.nansum(out[:, :1, :8]))
+
+
+def _cpu_identity():
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return model, os.cpu_count() or 1, usable
+
+
+def cpu_baseline(pool, n_workers, geom, vol, field_name, n_vox_total, max_pairs):
+    """Reference CPU path on a bounded sample: whole (z,y) rows around the centre of the grid, CSR rows copied from the
+    GPU-built geometry.  Two legs: (a) one thread -- what radar_grid/interpolate.py does; (b) one process per usable
+    core, each gridding its own block of rows of the same sample (how a host would batch independent work)."""
+    import shutil
+    import tempfile
     from oracle import radar_grid_oracle as oracle
     csr = geom.device_csr()
     nz, ny, nx = geom.grid_shape
-    ip_rows = csr.indptr[::nx].cpu().numpy().astype(np.int64)      # pair offset at the start of every y-row
+    ip_rows = csr.indptr[::nx].cpu().numpy().astype(np.int64)      # pair offset at the start of every (z,y) row
     n_rows = nz * ny
     centre = (nz // 2) * ny + ny // 2
-    # widest window of whole y-rows around the grid centre that stays under the pair budget (bisection)
+    # widest window of whole rows around the grid centre that stays under the pair budget (bisection)
     h_lo, h_hi = 1, max(centre, n_rows - centre)
     while h_lo < h_hi:
         h = (h_lo + h_hi + 1) // 2
@@ -94,45 +198,126 @@ def cpu_baseline(geom, vol, field_name, n_vox_total, max_pairs):
     pairs = p1 - p0
     pairs_per_s = pairs / dt
     total_pairs = csr.n_pairs
-    full_grid_s = total_pairs / pairs_per_s
-    return {
-        "value": round(n_vox_total / full_grid_s / 1e6, 4),
-        "unit": "Mvoxel/s",
-        "cores": 1,
-        "kind": "port",
-        "sample": (f"NumPy restatement of apply_geometry (oracle.csr_apply, 1 thread) on y-rows [{r0},{r1}) of the "
-                   f"bench grid's {n_rows} (z,y) rows around its centre: {v1 - v0} voxels, {pairs} CSR pairs in {dt:.2f} s = {pairs_per_s / 1e6:.1f} Mpairs/s; "
-                   f"value = full-grid voxels / (all {total_pairs} pairs / that rate)"),
+    model, logical, usable = _cpu_identity()
+    single = {
+        "value": round(n_vox_total / (total_pairs / pairs_per_s) / 1e6, 4), "unit": "Mvoxel/s", "cores": 1,
+        "mpairs_per_s": round(pairs_per_s / 1e6, 2), "seconds": round(dt, 2),
         "sample_mvoxel_per_s": round((v1 - v0) / dt / 1e6, 4),
-        "mpairs_per_s": round(pairs_per_s / 1e6, 2),
     }
+    sample = (f"NumPy restatement of apply_geometry (oracle.csr_apply) on (z,y) rows [{r0},{r1}) of the bench grid's "
+              f"{n_rows} around its centre: {v1 - v0} voxels, {pairs} CSR pairs; value = full-grid voxels / (all "
+              f"{total_pairs} pairs / measured pair rate)")
+    result = {"value": single["value"], "unit": "Mvoxel/s", "cores": 1, "kind": "port", "sample": sample,
+              "cpu_model": model, "os_cpu_count": logical, "usable_cores": usable, "single_thread": single,
+              "all_cores": None}
+    if pool is None:
+        return result
+    # ---- all-core leg: the same sample, split into one block of rows per worker (equal pair counts) -------------
+    workers = n_workers
+    tmp = tempfile.mkdtemp(prefix="rg_cpu_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        np.save(os.path.join(tmp, "indptr.npy"), indptr)
+        np.save(os.path.join(tmp, "gidx.npy"), gidx)
+        np.save(os.path.join(tmp, "wts.npy"), wts)
+        np.save(os.path.join(tmp, "data.npy"), np.ascontiguousarray(data))
+        np.save(os.path.join(tmp, "mask.npy"), np.ascontiguousarray(mask))
+        del gidx, wts
+        row_pairs = indptr[::nx]
+        cuts = np.searchsorted(row_pairs, np.linspace(0, pairs, workers + 1)[1:-1])
+        edges = [0, *[int(c) for c in cuts], r1 - r0]
+        jobs = [(tmp, edges[i], edges[i + 1], nx) for i in range(workers) if edges[i + 1] > edges[i]]
+        pool.map(_cpu_worker, [(tmp, 0, 1, nx)] * workers)            # import NumPy / the oracle in every worker
+        best = None
+        for _ in range(2):       # all workers run concurrently; the leg takes as long as its slowest worker computes
+            done = pool.map(_cpu_worker, jobs, chunksize=1)
+            slowest = max(d[1] for d in done)
+            best = slowest if best is None else min(best, slowest)
+        rate = sum(d[0] for d in done) / best
+        result["all_cores"] = {
+            "value": round(n_vox_total / (total_pairs / rate) / 1e6, 4), "unit": "Mvoxel/s", "cores": len(jobs),
+            "mpairs_per_s": round(rate / 1e6, 2), "seconds": round(best, 2),
+            "how": "one process per usable core (multiprocessing spawn), NumPy single-threaded, each gridding its own "
+                   "block of whole rows of the sample (equal pair counts), all at once; compute time of the slowest worker, best of 2",
+        }
+        result["value"], result["cores"] = result["all_cores"]["value"], len(jobs)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return result
 
 
 def pmc_traffic(workload: str):
-    """HBM bytes per csr_apply launch from rocprofv3 PMC passes (profiles/pmc_traffic.json, committed with the
-    rocprof CSVs it was derived from); None when no measurement exists for this workload."""
+    """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (profiles/pmc_traffic.json, committed with
+    the rocprof CSVs it was derived from); (None, reason) when no measurement exists for this workload."""
     path = os.path.join(REPO, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
             table = json.load(f)
-        return table.get(workload, {}).get("hbm_bytes_per_launch")
+        rec = table.get(workload)
+        if rec:
+            return rec.get("hbm_bytes_per_launch"), (f"profiles/pmc_traffic.json[{workload!r}] -- rocprofv3 --pmc FETCH_SIZE / "
+                                                      f"WRITE_SIZE passes of this command ({rec.get('tag', 'tag n/a')}), "
+                                                      "not collected during this run")
     except Exception:
+        pass
+    return None, "no committed PMC pass for this workload"
+
+
+def measured_read_ceiling(torch, rg, dev, buffers):
+    """Read bandwidth a pure streaming kernel gets on THIS box right now (rg_stream_read_probe over the largest
+    resident buffer, best of 5 after a warm-up).  Untimed side measurement, outside the timed region."""
+    from radar_processor_amd import _native
+    lib = rg.load_library()
+    buf = max((b for b in buffers if b is not None and b.numel() > 0), key=lambda b: b.numel() * b.element_size(),
+              default=None)
+    if buf is None:
         return None
+    nbytes = (buf.numel() * buf.element_size()) // 16 * 16
+    if nbytes < (1 << 28):                       # a small geometry would measure the Infinity Cache, not HBM
+        scratch = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+        buf, nbytes = scratch, scratch.numel()
+    sink = torch.zeros(4, dtype=torch.float32, device=dev)
+    best = None
+    for i in range(6):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _native.check(lib.rg_stream_read_probe(_native.ptr(buf), nbytes, _native.ptr(sink), _native.stream_ptr()),
+                      "rg_stream_read_probe")
+        e1.record()
+        e1.synchronize()
+        if i:
+            ms = e0.elapsed_time(e1)
+            best = ms if best is None else min(best, ms)
+    return nbytes / (best * 1e-3) / 1e9
 
 
-def main():
-    args = parse_args()
-    import torch
-    import torch.distributed as dist
-    import radar_processor_amd as rg
-    from radar_processor_amd import synthetic
-    from radar_processor_amd.gridding import CsrGridder
-
+# ---------------------------------------------------------------------------------------------------------------
+def run_rank(args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        log(f"WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+    if world != args.gpus:
+        log(f"WORLD_SIZE={world} but --gpus {args.gpus}: start this script as `python bench.py --gpus {args.gpus}` (it "
+            f"spawns its own ranks) or under `python -m torch.distributed.run --nproc-per-node {args.gpus}`")
+        return 2
+
+    # ---- everything that creates processes happens BEFORE the GPU is touched ---------------------------------
+    from radar_processor_amd.build import ensure_built
+    ensure_built(verbose=rank == 0)              # bare checkout: compile the git-ignored library (file-locked)
+    pool, n_workers = None, 1
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode == "csr"
+    if want_cpu:
+        import multiprocessing as mp
+        _, _, usable = _cpu_identity()
+        n_workers = args.cpu_workers or usable
+        if n_workers > 1:
+            pool = mp.get_context("spawn").Pool(n_workers)
+
+    import torch
+    import torch.distributed as dist
+    import radar_processor_amd as rg
+    from radar_processor_amd import batch, synthetic
+    from radar_processor_amd.gridding import CsrGridder
+
     n_gpus = world
     dev_index = 0 if args.share_device else local_rank
     torch.cuda.set_device(dev_index)
@@ -143,55 +328,63 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)      # RCCL over xGMI
         else:
             dist.init_process_group(backend="gloo")
-    if local_rank == 0:
-        from radar_processor_amd.build import ensure_built
-        ensure_built(verbose=rank == 0)          # bare checkout: compile the git-ignored library once per node
-    if world > 1:
-        dist.barrier()
+        assert dist.get_world_size() == world
     rg.load_library()
 
-    cfg = synthetic.CONFIGS[args.config]
+    c5 = args.config == "C5"
+    cfg = dict(synthetic.CONFIGS["C2" if c5 else args.config])
+    if c5:
+        cfg["grid_shape"] = synthetic.CONFIGS[args.c5_grid]["grid_shape"]
+        cfg["grid_limits"] = synthetic.CONFIGS[args.c5_grid]["grid_limits"]
     field_names = ("DBZH", "ZDR", "RHOHV")[:max(1, min(3, args.fields))]
     n_f = len(field_names)
-    n_vol = max(1, args.volumes_per_gpu)
-    if n_f * n_vol > 8:
+    n_vol = max(1, args.volumes_per_gpu if args.volumes_per_gpu is not None else (8 if c5 else 1))
+    if not c5 and n_f * n_vol > 8:
         raise SystemExit("fields x volumes-per-gpu must be <= 8 (one fused pass)")
     shape, limits = cfg["grid_shape"], cfg["grid_limits"]
     n_vox = int(np.prod(shape))
 
     # ---- synthetic inputs, resident in HBM before the timed region ------------------------------------
     t0 = time.perf_counter()
-    vols = [synthetic.make_volume(cfg["n_elev"], cfg["n_az"], cfg["n_gates"], seed=rank * n_vol + b, fields=field_names)
-            for b in range(n_vol)]
-    vol = vols[0]
+    total_vol = n_vol * world
+    my_vols = batch.shard_indices(total_vol, rank, world)           # volume b -> rank b mod N; seed = b
+    vols = {b: synthetic.make_volume(cfg["n_elev"], cfg["n_az"], cfg["n_gates"], seed=b, fields=field_names)
+            for b in my_vols}
+    vol = vols[my_vols[0]]
     n_gates = vol.n_total_gates
-    fields_d, masks_d = [], []
-    for v in vols:
+    fields_d, masks_d, dev_volumes = [], [], [None] * total_vol
+    for b in my_vols:
+        entry = {}
         for name in field_names:
-            fields_d.append(torch.from_numpy(np.ascontiguousarray(np.ma.getdata(v.fields[name]))).to(dev))
-            masks_d.append(torch.from_numpy(np.ma.getmaskarray(v.fields[name]).astype(np.uint8)).to(dev))
+            f_t = torch.from_numpy(np.ascontiguousarray(np.ma.getdata(vols[b].fields[name]))).to(dev)
+            m_t = torch.from_numpy(np.ma.getmaskarray(vols[b].fields[name]).astype(np.uint8)).to(dev)
+            fields_d.append(f_t)
+            masks_d.append(m_t)
+            entry[name] = (f_t, m_t)
+        dev_volumes[b] = entry
     shared = None
-    if "RHOHV" in field_names:      # config 3: RHOHV >= 0.8 QC mask shared by all fields, evaluated on the device
+    if "RHOHV" in field_names and not c5:   # config 3: RHOHV >= 0.8 QC mask shared by all fields, on the device
         shared = rg.device_gate_mask(fields_d[field_names.index("RHOHV")], "below", 0.8)
-    log(f"rank {rank}: synthetic volume(s) {cfg['n_elev']}x{cfg['n_az']}x{cfg['n_gates']} ready in {time.perf_counter() - t0:.1f}s")
+    log(f"rank {rank}: {len(my_vols)} synthetic volume(s) {cfg['n_elev']}x{cfg['n_az']}x{cfg['n_gates']} ready in "
+        f"{time.perf_counter() - t0:.1f}s")
 
     # ---- geometry (once per scan strategy; untimed) -----------------------------------------------------
     t0 = time.perf_counter()
     n_ff = n_f * n_vol
-    out = torch.empty((n_ff, n_vox), dtype=torch.float32, device=dev)
+    gridder = search = None
     if args.mode == "csr":
-        search = None
         import tempfile
         with tempfile.TemporaryDirectory() as tmp:
-            # single field-volume passes use the compact copy of the CSR; 'auto' keeps the reference's index array
-            # next to it when both fit and builds the copy alone otherwise (config 4: 33 G pairs)
-            want_compact = n_ff == 1 and not args.no_compact
+            # single-field passes use the compact copy of the CSR; 'auto' keeps the reference's index array next to it
+            # when both fit and builds the copy alone otherwise (config 4: 33 G pairs)
+            fields_per_pass = min(8, n_ff)     # C5: VolumeBatch fuses up to 8 field-volumes into one pass
+            want_compact = fields_per_pass == 1 and not args.no_compact
             geom = rg.compute_grid_geometry(vol.gate_x, vol.gate_y, vol.gate_z, shape, limits, tmp,
                                             layout="auto" if want_compact else "csr")
         if want_compact and geom.device_csr(dev).gate_indices is not None:
             free_b, _ = torch.cuda.mem_get_info(dev)              # room for the copy (2.3 bytes per pair + scratch)?
             want_compact = free_b > 3.2 * geom.n_pairs() + (8 << 30)
-        gridder = CsrGridder(geom, n_gates, n_ff, device=dev, compact=want_compact)
+        gridder = CsrGridder(geom, n_gates, fields_per_pass, device=dev, compact=want_compact)
         n_pairs = gridder.csr.n_pairs
         ref_format_bytes = gridder.algorithmic_bytes()          # 8 bytes per pair
         if gridder.compact is not None:
@@ -200,39 +393,55 @@ def main():
         else:
             algo_bytes = ref_format_bytes
             kernel_name = "csr_apply_dyn_kernel"
+        batch_geometry = geom
     else:
         from radar_processor_amd.roi_grid import roi_grid_fields_device
         search = rg.RoiSearch(vol.gate_x, vol.gate_y, vol.gate_z, shape, limits, device=dev)
         geom = rg.GridGeometry(shape, limits, None, None, None, toa=17000.0)
         n_pairs = None
-        algo_bytes = (12 + 5 * n_ff) * n_gates + 4 * n_ff * n_vox
+        fields_per_pass = min(8, n_ff)
+        algo_bytes = (12 + 5 * fields_per_pass) * n_gates + 4 * fields_per_pass * n_vox
         ref_format_bytes = algo_bytes
         kernel_name = "roi_block_kernel"
+        batch_geometry = search
     torch.cuda.synchronize()
     t_geom = time.perf_counter() - t0
     log(f"rank {rank}: geometry ({args.mode}) ready in {t_geom:.1f}s"
         + (f": {n_pairs:,} pairs ({n_pairs / n_vox:.1f}/voxel), {algo_bytes / 1e9:.2f} GB algorithmic per launch" if n_pairs else ""))
 
-    grid4 = out.view(n_ff, *shape)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    events = []                                   # (start, end) per gridding launch inside the timed region
 
-    def step(i=None):
-        if args.mode == "csr":
-            gridder.pack(fields_d, masks_d, shared)
-            if i is not None:
-                ev[i][0].record()
-            gridder.apply(out)
-            if i is not None:
-                ev[i][1].record()
-        else:
-            if i is not None:
-                ev[i][0].record()
-            roi_grid_fields_device(search, fields_d, masks_d, shared_mask=shared, out=grid4)
-            if i is not None:
-                ev[i][1].record()
-        for k in range(n_ff):
-            rg.column_argmax(grid4[k])
-            rg.constant_altitude_ppi(grid4[k], geom, 4000.0)
+    if c5:
+        vb = batch.VolumeBatch(batch_geometry, field_names, device=dev)
+
+        def reducer(g):
+            return [(rg.column_argmax(g[k]), rg.constant_altitude_ppi(g[k], geom, 4000.0)) for k in range(g.shape[0])]
+
+        def step(timed=False):
+            return vb.grid_shard(dev_volumes, products=reducer, rank=rank, world_size=world,
+                                 events=events if timed else None)
+    else:
+        out = torch.empty((n_ff, n_vox), dtype=torch.float32, device=dev)
+        grid4 = out.view(n_ff, *shape)
+
+        def step(timed=False):
+            if timed:
+                pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            if args.mode == "csr":
+                gridder.pack(fields_d, masks_d, shared)
+                if timed:
+                    pair[0].record()
+                gridder.apply(out)
+            else:
+                if timed:
+                    pair[0].record()
+                roi_grid_fields_device(search, fields_d, masks_d, shared_mask=shared, out=grid4)
+            if timed:
+                pair[1].record()
+                events.append(pair)
+            for k in range(n_ff):
+                rg.column_argmax(grid4[k])
+                rg.constant_altitude_ppi(grid4[k], geom, 4000.0)
 
     def barrier():
         torch.cuda.synchronize()
@@ -244,25 +453,28 @@ def main():
         step()
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
+    for _ in range(args.steps):
+        step(True)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else float("nan")
+    launches_per_step = len(events) / max(args.steps, 1)
 
-    result = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = n_gpus * n_ff * n_vox / (elapsed / args.steps) / 1e6
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         workload = (f"{cfg['n_elev']}x{cfg['n_az']}x{cfg['n_gates']}-gate volume -> {shape[0]}x{shape[1]}x{shape[2]} grid, "
-                    f"{'+'.join(field_names)}, {n_vol} volume(s)/GPU/step, mode={args.mode}")
+                    f"{'+'.join(field_names)}, {n_vol} volume(s)/GPU/step"
+                    + (f" (BASELINE config 5: {total_vol} seeded volumes, volume b -> rank b mod {world}, through "
+                       f"batch.VolumeBatch)" if c5 else "") + f", mode={args.mode}")
         compact_on = args.mode == "csr" and gridder.compact is not None
         workload_key = f"{args.config}/{'csr_compact' if compact_on else args.mode}/F{n_f}/B{n_vol}"
+        traffic, traffic_source = pmc_traffic(workload_key)
         result = {
             "metric": "Mvoxels/s gridded (+ achieved HBM GB/s in roofline)",
             "value": round(value, 2),
@@ -277,7 +489,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": workload, "key": workload_key, "gates": n_gates, "voxels": n_vox,
-                       "pairs": n_pairs, "fields_per_pass": n_ff,
+                       "pairs": n_pairs, "fields_per_pass": fields_per_pass, "volumes_total": total_vol,
+                       "ranks_seen_by_process_group": dist.get_world_size() if world > 1 else 1,
                        "step": "pack_fields + " + (("csr_compact_apply" if compact_on else "csr_apply") if args.mode == "csr"
                                                    else "roi_grid")
                                + " + colmax/argmax + cappi4000 per field-volume"},
@@ -288,16 +501,53 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": pmc_traffic(workload_key),
+                "traffic": traffic,
+                "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": int(algo_bytes),
                 "kernel_ms": round(kernel_ms, 4),
+                "launches_per_step": launches_per_step,
                 # the same launch priced in the reference's CSR format (8 bytes per pair); larger than
                 # `achieved` when the compact device copy is in use, because that kernel moves fewer bytes per pair
                 "reference_format_bytes_per_launch": int(ref_format_bytes),
                 "reference_format_GBps": round(ref_format_bytes / (kernel_ms * 1e-3) / 1e9, 1),
             },
         }
-        if n_gpus == 1 and args.mode == "csr":
+        try:        # what a pure streaming read gets on this box, same process, outside the timed region
+            csr_now = gridder.csr if gridder is not None else None
+            ceiling = measured_read_ceiling(torch, rg, dev, [csr_now.weights if csr_now is not None else None,
+                                                             search.sorted_gates if search is not None else None])
+            if ceiling:
+                result["roofline"]["ceiling_measured"] = round(ceiling, 1)
+                result["roofline"]["frac_of_ceiling"] = round(achieved / ceiling, 4)
+                result["roofline"]["ceiling_how"] = ("rg_stream_read_probe: grid-stride dwordx4 read of the largest resident "
+                                                     "buffer, no stores, best of 5, same process, untimed")
+        except Exception as exc:
+            log(f"ceiling probe failed: {exc!r}")
+        if c5:
+            # end-to-end leg: the same shard with the fields uploaded from page-locked host memory and the
+            # 2-D product planes downloaded inside the timed region -- reported next to `value`, never as `value`
+            try:
+                host_vols = [None] * total_vol
+                for b in my_vols:
+                    host_vols[b] = {k: (v[0].cpu().pin_memory(), v[1].cpu().pin_memory()) for k, v in dev_volumes[b].items()}
+
+                def to_host(g):
+                    return [(a[0].cpu(), a[1].cpu(), c.cpu()) for a, c in reducer(g)]
+                vb.grid_shard(host_vols, products=to_host, rank=rank, world_size=world)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                reps = 3
+                for _ in range(reps):
+                    vb.grid_shard(host_vols, products=to_host, rank=rank, world_size=world)
+                torch.cuda.synchronize()
+                e2e = (time.perf_counter() - t1) / reps
+                result["end_to_end"] = {"ms_per_step": round(e2e * 1e3, 3),
+                                        "mvoxel_s_this_rank": round(n_ff * n_vox / e2e / 1e6, 1),
+                                        "what": "H2D of fields+masks from pinned host memory, gridding, COLMAX/argmax/CAPPI, "
+                                                "D2H of the 2-D planes; rank 0 only"}
+            except Exception as exc:
+                log(f"end-to-end leg failed: {exc!r}")
+        if n_gpus == 1 and args.mode == "csr" and not c5:
             # side measurement on the same inputs (not part of `value`): the CSR-free fused gridder (K2)
             try:
                 from radar_processor_amd.roi_grid import roi_grid_fields_device
@@ -317,18 +567,31 @@ def main():
                 del search
             except Exception as exc:
                 log(f"fused side measurement failed: {exc!r}")
-        if n_gpus == 1 and not args.no_cpu_baseline and args.mode == "csr":
-            log("timing the CPU baseline (NumPy port, 1 core) on a bounded sample ...")
+        if want_cpu:
+            log("timing the CPU baseline (NumPy port: 1 thread, then all usable cores) on a bounded sample ...")
             try:
-                result["cpu_baseline"] = cpu_baseline(geom, vol, field_names[0], n_vox, args.cpu_sample_pairs)
+                result["cpu_baseline"] = cpu_baseline(pool, n_workers, geom, vol, field_names[0], n_vox, args.cpu_sample_pairs)
             except Exception as exc:   # never lose the GPU line to a host-side problem
                 log(f"cpu baseline failed: {exc!r}")
                 result["cpu_baseline"] = None
         print(json.dumps(result), flush=True)
+    if pool is not None:
+        pool.close()
+        pool.join()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return spawn_ranks(args)             # the parent never touches the GPU
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

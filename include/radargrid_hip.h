@@ -55,6 +55,10 @@ int rg_version(void);
 const char* rg_last_error(void);
 /* number of visible HIP devices, or RG_ENODEVICE */
 int rg_device_count(void);
+/* measurement aid (no reference counterpart): streams `bytes` of `buffer` with 16-byte loads and stores nothing
+ * (`sink` = one float the kernel never writes in practice); bench.py times it to report the read bandwidth this
+ * GPU delivers to a pure streaming kernel next to the 8 TB/s spec peak (roofline.ceiling_measured). */
+int rg_stream_read_probe(const void* buffer, int64_t bytes, float* sink, rg_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * a1  antenna -> Cartesian (PyART antenna_vectors_to_cartesian, call sites radar_grid/utils.py:35-37).
@@ -96,7 +100,11 @@ int rg_pack_fields_f32(int32_t n_fields, const float* const* fields_host, const 
  * of :137-140 (apply_geometry_multi) with ONE pass over the CSR for all n_fields field-volumes.
  *   out[f*n_vox + v] = sum_j w_j*val_f(g_j) / sum_j w_j   over pairs j of row v whose gate is not EXCLUDED
  *                      for field f, if that weight sum is > 0; otherwise fill_value.
- * Products are float32 (as in the reference), sums are accumulated in float64 and rounded once.
+ * Arithmetic: float32 products and float32 sums (as the reference under NumPy >= 2), added in a fixed,
+ * launch-independent order (per 64-row segment: tiles of pairs, a few interleaved partial sums per row, combined with
+ * wavefront shuffles) -- bit-reproducible run to run, not NumPy's pairwise order; only the final division is done in
+ * float64 and rounded to float32.  Worst relative deviation from the reference's grids on the golden fixtures is recorded
+ * by tests/test_gpu_parity.py::test_reference_grid_relative_error (a few float32 ulps).
  * the gather goes through a range-checked buffer resource of n_gates * stride * 4 bytes (which must stay below
  * 4 GiB): a gate index outside [0, n_gates) reads as 0.0 and cannot fault the GPU.
  * indptr must be non-decreasing with indptr[0] = 0 and indptr[n_vox] = n_pairs.
@@ -200,8 +208,8 @@ int rg_geom_fill_f32(const rg_gate4* sorted_gates, const int32_t* cell_start, co
  * K2  fused on-the-fly gridding: the neighbour search of rg_geom_count/fill_f32 fused with the masked
  * weighted mean of rg_csr_apply_f32 -- radar_grid/compute.py:46-91 + radar_grid/interpolate.py:69-104 in
  * one kernel, no CSR in memory (for grids whose pair count makes the CSR pointless or impossible,
- * SURVEY.md F6).  Same neighbour sets and weights as the builder; results differ from the CSR path only by
- * float64 summation order.  `packed` is the rg_pack_fields_f32 layout over the same gate numbering as the
+ * SURVEY.md F6).  Same neighbour sets as the builder, weights evaluated in float32 (|rel err| < 2e-6 vs the builder's
+ * float64-exact ones), float32 sums per voxel lane; results differ from the CSR path by that and by summation order.  `packed` is the rg_pack_fields_f32 layout over the same gate numbering as the
  * gates that were binned.
  * ------------------------------------------------------------------------------------------------- */
 int rg_roi_grid_f32(const rg_gate4* sorted_gates, const int32_t* cell_start, const rg_cellgrid* cells_host,

@@ -51,6 +51,7 @@ SIGNATURES = {
     "rg_version": (c_int32, []),
     "rg_last_error": (c_char_p, []),
     "rg_device_count": (c_int32, []),
+    "rg_stream_read_probe": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p]),
     "rg_antenna_to_cartesian_f32": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
                                               c_void_p, c_void_p]),
     "rg_gate_mask_f32": (c_int32, [c_void_p, c_int64, c_int32, c_float, c_float, c_void_p, c_void_p]),

@@ -135,9 +135,12 @@ class VolumeBatch:
         return a.to(device=self.dev, dtype=dtype).contiguous()
 
     def grid_shard(self, volumes: Sequence[dict], products: Optional[Callable] = None, rank=None,
-                   world_size=None) -> Dict[int, object]:
+                   world_size=None, events: Optional[list] = None) -> Dict[int, object]:
         """Returns ``{volume index: grids [F, nz, ny, nx]}`` -- or ``{index: products(grids)}`` when a reducer is
-        given, so that only 2-D planes outlive the pass."""
+        given, so that only 2-D planes outlive the pass.  ``volumes`` is indexed by the GLOBAL volume number; only this
+        rank's entries (``shard_indices``) are touched, the others may be ``None``.  ``events``: optional list that
+        receives one ``(start, end)`` pair of stream events per gridding pass (mask fold + gridding kernel), for
+        callers that time the kernel itself (``bench.py``)."""
         import torch
         from .gridding import grid_fields_device
         from .roi_grid import roi_grid_fields_device
@@ -152,10 +155,16 @@ class VolumeBatch:
                     values, mask = volumes[b][name]
                     fields.append(self._to_dev(values, torch.float32))
                     masks.append(self._to_dev(mask, torch.uint8))
+            if events is not None:
+                pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                pair[0].record()
             if self.fused:
                 grids = roi_grid_fields_device(self.geometry, fields, masks, weighting=self.weighting)
             else:
                 grids = grid_fields_device(self.geometry, fields, masks)
+            if events is not None:
+                pair[1].record()
+                events.append(pair)
             for i, b in enumerate(group):
                 g = grids[i * n_f:(i + 1) * n_f]
                 out[b] = products(g) if products is not None else g

@@ -82,9 +82,17 @@ def ensure_built(verbose: bool = True) -> str:
     the entry points that own a process -- tests, ``bench.py``, ``smoke()`` -- never by the product path, which keeps
     failing loudly when the library is missing."""
     if not os.path.exists(LIB_PATH):
-        if verbose:
-            print(f"[build] {LIB_PATH} is missing: compiling it now (hipcc, {ARCH})", flush=True)
-        build(verbose=verbose)
+        import fcntl
+        # several ranks of one node may get here together: one compiles, the others wait on the lock and find it built
+        with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                if not os.path.exists(LIB_PATH):
+                    if verbose:
+                        print(f"[build] {LIB_PATH} is missing: compiling it now (hipcc, {ARCH})", flush=True)
+                    build(verbose=verbose)
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 

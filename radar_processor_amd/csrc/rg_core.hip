@@ -183,3 +183,36 @@ extern "C" int rg_pack_fields_f32(int32_t n_fields, const float* const* fields_h
   }
   return rg::check_launch("rg_pack_fields_f32");
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Measurement aid (bench.py's roofline.ceiling_measured): what read bandwidth does this GPU deliver to a kernel that
+// only streams a large array?  Grid-stride dwordx4 reads, four independent loads in flight per lane, no stores.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void stream_read_kernel(const float4* __restrict__ a, long n16,
+                                                          float* __restrict__ sink) {
+  float acc = 0.0f;
+  const long stride = (long)gridDim.x * blockDim.x;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n16; i += 4 * stride) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = a[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc += v[u].x + v[u].y + v[u].z + v[u].w;
+  }
+  for (; i < n16; i += stride) {
+    const float4 v = a[i];
+    acc += v.x + v.y + v.z + v.w;
+  }
+  if (acc == 123.456f) sink[0] = acc;   // practically never true: keeps the loads alive without a store stream
+}
+}  // namespace
+
+extern "C" int rg_stream_read_probe(const void* buffer, int64_t bytes, float* sink, rg_stream_t stream) {
+  RG_REQUIRE(buffer && sink && bytes >= 16, RG_EINVAL, "rg_stream_read_probe: null buffer/sink or fewer than 16 bytes");
+  RG_REQUIRE(rg::aligned16(buffer), RG_EALIGN, "rg_stream_read_probe: buffer must be 16-byte aligned");
+  hipLaunchKernelGGL(stream_read_kernel, dim3(8192), dim3(256), 0, (hipStream_t)stream,
+                     static_cast<const float4*>(buffer), (long)(bytes / 16), sink);
+  return rg::check_launch("rg_stream_read_probe");
+}

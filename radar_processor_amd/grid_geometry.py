@@ -197,13 +197,35 @@ class GridGeometry:
             setattr(self, "_" + name, arr)
         return arr
 
+    def _assign(self, name: str, value) -> None:
+        """Plain attribute assignment, as on the reference dataclass: the other two arrays are pulled to the host
+        first (a device-built geometry holds its only copy in HBM), then every device-side cache -- the resident
+        CSR and its compact copy -- is dropped, so the next gridding call uploads and validates the new arrays."""
+        if self._dev is not None:
+            for other in ("indptr", "gate_indices", "weights"):
+                if other != name:
+                    self._host(other)
+        setattr(self, "_" + name, value)
+        self.invalidate_device()
+
+    def invalidate_device(self) -> None:
+        """Forget the device-resident copies (CSR, compact copy, cached gridders).  Call this after modifying the host
+        arrays IN PLACE: ``device_csr`` otherwise keeps serving the arrays it uploaded the first time."""
+        if self._dev is not None:
+            for name in ("indptr", "gate_indices", "weights"):
+                self._host(name)
+        self._dev = None
+        self.__dict__.pop("_compact", None)
+        self.__dict__.pop("_gridders", None)
+        self.__dict__.pop("_single_field_passes", None)
+
     @property
     def indptr(self) -> np.ndarray:
         return self._host("indptr")
 
     @indptr.setter
     def indptr(self, value):
-        self._indptr, self._dev = value, None
+        self._assign("indptr", value)
 
     @property
     def gate_indices(self) -> np.ndarray:
@@ -211,7 +233,7 @@ class GridGeometry:
 
     @gate_indices.setter
     def gate_indices(self, value):
-        self._gate_indices, self._dev = value, None
+        self._assign("gate_indices", value)
 
     @property
     def weights(self) -> np.ndarray:
@@ -219,7 +241,7 @@ class GridGeometry:
 
     @weights.setter
     def weights(self, value):
-        self._weights, self._dev = value, None
+        self._assign("weights", value)
 
     @property
     def is_device_resident(self) -> bool:

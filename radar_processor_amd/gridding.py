@@ -103,13 +103,15 @@ class CsrGridder:
         if len(fields) != self.n_fields:
             raise ValueError(f"expected {self.n_fields} fields, got {len(fields)}")
         for i, f in enumerate(fields):
-            if not (f.is_cuda and f.dtype == torch.float32 and f.is_contiguous() and f.numel() == self.n_gates):
-                raise ValueError(f"field {i}: expected a contiguous cuda float32 tensor of {self.n_gates} gates")
+            if not (f.is_cuda and f.device == self.packed.device and f.dtype == torch.float32 and f.is_contiguous()
+                    and f.numel() == self.n_gates):
+                raise ValueError(f"field {i}: expected a contiguous cuda float32 tensor of {self.n_gates} gates "
+                                 f"on {self.packed.device}")
         if len(masks) != self.n_fields:
             raise ValueError("masks must have one entry (tensor or None) per field")
         for i, m in enumerate(list(masks) + [shared_mask]):
-            if m is not None and not (m.is_cuda and m.dtype == torch.uint8 and m.is_contiguous()
-                                      and m.numel() == self.n_gates):
+            if m is not None and not (m.is_cuda and m.device == self.packed.device and m.dtype == torch.uint8
+                                      and m.is_contiguous() and m.numel() == self.n_gates):
                 raise ValueError(f"mask {i}: expected a contiguous cuda uint8 tensor of {self.n_gates} gates")
 
     def pack(self, fields: Sequence, masks: Optional[Sequence] = None, shared_mask=None) -> None:
@@ -176,6 +178,21 @@ def _use_compact(geometry: GridGeometry, dev) -> bool:
     return free_b > 3.2 * n_pairs + (8 << 30)
 
 
+def _cached_gridder(geometry: GridGeometry, n_gates: int, n_fields: int, dev, compact: bool) -> "CsrGridder":
+    """One :class:`CsrGridder` (and its packed-field staging buffer) per (device CSR, gate count, field count, kernel)
+    of a geometry, kept on the geometry object: repeated ``apply_geometry`` calls allocate nothing.  The cache dies with
+    the device copy (``GridGeometry.invalidate_device`` / attribute assignment)."""
+    csr = geometry.device_csr(dev)
+    cache = geometry.__dict__.setdefault("_gridders", {})
+    key = (id(csr), int(n_gates), int(n_fields), bool(compact))
+    gridder = cache.get(key)
+    if gridder is None or gridder.csr is not csr:
+        if len(cache) >= 8:                 # a handful of shapes per geometry is the norm; never grow without bound
+            cache.clear()
+        gridder = cache[key] = CsrGridder(geometry, n_gates, n_fields, device=dev, compact=compact)
+    return gridder
+
+
 def grid_fields_device(geometry: GridGeometry, fields: Sequence, masks: Optional[Sequence] = None,
                        shared_mask=None, fill_value: float = np.nan, out=None):
     """Grid ``len(fields)`` device-resident fields with one CSR pass per group of up to 8.
@@ -210,8 +227,8 @@ def grid_fields_device(geometry: GridGeometry, fields: Sequence, masks: Optional
     with torch.cuda.device(dev):
         for f0 in range(0, n_fields, _native.RG_MAX_FIELDS):
             f1 = min(n_fields, f0 + _native.RG_MAX_FIELDS)
-            gridder = CsrGridder(geometry, n_gates, f1 - f0, device=dev,
-                                 compact=n_fields == 1 and _use_compact(geometry, dev))
+            gridder = _cached_gridder(geometry, n_gates, f1 - f0, dev,
+                                      compact=n_fields == 1 and _use_compact(geometry, dev))
             gridder.pack(fields[f0:f1], masks[f0:f1], shared_mask)
             gridder.apply(out.view(n_fields, n_vox)[f0:f1], fill_value)
     return out.view(n_fields, nz, ny, nx)

@@ -32,17 +32,25 @@ def roi_grid_fields_device(search: RoiSearch, fields: Sequence, masks: Optional[
     dev = search.dev
     n_gates = search.n_gates
     for i, f in enumerate(fields):
-        if not (f.is_cuda and f.dtype == torch.float32 and f.is_contiguous() and f.numel() == n_gates):
-            raise ValueError(f"field {i}: expected a contiguous cuda float32 tensor of {n_gates} gates")
+        if not (f.is_cuda and f.device == dev and f.dtype == torch.float32 and f.is_contiguous()
+                and f.numel() == n_gates):
+            raise ValueError(f"field {i}: expected a contiguous float32 tensor of {n_gates} gates on {dev}")
     if masks is None:
         masks = [None] * n_fields
+    if len(masks) != n_fields:
+        raise ValueError("masks must have one entry (tensor or None) per field")
     for i, m in enumerate(list(masks) + [shared_mask]):
-        if m is not None and not (m.is_cuda and m.dtype == torch.uint8 and m.is_contiguous() and m.numel() == n_gates):
-            raise ValueError(f"mask {i}: expected a contiguous cuda uint8 tensor of {n_gates} gates")
+        if m is not None and not (m.is_cuda and m.device == dev and m.dtype == torch.uint8 and m.is_contiguous()
+                                  and m.numel() == n_gates):
+            raise ValueError(f"mask {i}: expected a contiguous uint8 tensor of {n_gates} gates on {dev}")
     nz, ny, nx = search.grid_shape
     n_vox = nz * ny * nx
     if out is None:
         out = torch.empty((n_fields, nz, ny, nx), dtype=torch.float32, device=dev)
+    elif not (out.is_cuda and out.device == dev and out.dtype == torch.float32 and out.is_contiguous()
+              and out.numel() == n_fields * n_vox):
+        # the kernel writes n_fields * n_vox floats through a raw pointer: anything else is an out-of-bounds write
+        raise ValueError(f"out must be a contiguous float32 tensor of shape [F, nz, ny, nx] on {dev}")
     fill = float(np.float32(fill_value))
     with torch.cuda.device(dev):
         stream = _native.stream_ptr()

@@ -226,13 +226,75 @@ def gen_g6(ref, synth):
     print("g6", geom)
 
 
+def _sha(a) -> str:
+    import hashlib
+    a = np.ascontiguousarray(a)
+    return hashlib.sha256(a.tobytes()).hexdigest() + f":{a.dtype.str}:{a.shape}"
+
+
+def gen_g8(ref, synth):
+    """``.npz`` interchange (geometry.py:94-150), both directions:
+
+    * ``g8_ref_saved_geometry.npz`` is the file the REFERENCE's ``save_geometry`` wrote for a small geometry built by
+      the reference's ``compute_grid_geometry`` (an output file of the reference = data); the tests load it with this
+      build's ``load_geometry`` and grid through it;
+    * this build's ``save_geometry`` writes the same geometry, the REFERENCE's ``load_geometry`` reads that file back and
+      the outcome (field-by-field equality with the reference's own object, per-array digests, the key sets of the two
+      files) is recorded in ``g8_interchange.npz`` together with the reference's gridded field.
+    """
+    import radar_processor_amd as rg
+    vol = synth.make_volume(n_elev=12, n_az=360, n_gates=1000, seed=8, fields=("DBZH",))
+    shape = (6, 12, 12)
+    limits = window_limits((47e3, -72e3), shape, 480.0, (500.0, 8000.0))
+    geom, out = run_window(ref, vol, shape, limits, "barnes2", radar_altitude=0.0, toa=12000.0, n_workers=2)
+    geom.radar_altitude = 312.5           # compute_grid_geometry drops it (compute.py:277-284); pin the key's round trip
+    ref_path = os.path.join(HERE, "g8_ref_saved_geometry.npz")
+    ref.geometry.save_geometry(geom, ref_path)                       # <- written by the reference
+    with np.load(ref_path) as z:
+        ref_keys = sorted(z.files)
+        ref_dtypes = {k: z[k].dtype.str for k in z.files}
+    with tempfile.TemporaryDirectory() as tmp:
+        ours = rg.GridGeometry(shape, limits, geom.indptr.copy(), geom.gate_indices.copy(), geom.weights.copy(),
+                               toa=12000.0, radar_altitude=312.5)
+        our_path = os.path.join(tmp, "written_by_this_build.npz")
+        rg.save_geometry(ours, our_path)                             # <- written by this build
+        with np.load(our_path) as z:
+            our_keys = sorted(z.files)
+            our_dtypes = {k: z[k].dtype.str for k in z.files}
+        back = ref.geometry.load_geometry(our_path)                  # <- read by the reference
+        radar = vol.as_radar()
+        fdata = ref.utils.get_field_data(radar, "DBZH")
+        fdata = np.ma.array(np.ma.getdata(fdata), mask=np.ma.getmaskarray(fdata))
+        grid_back = ref.interpolate.apply_geometry(back, fdata)
+    same = dict(
+        grid_shape=tuple(int(v) for v in back.grid_shape) == tuple(shape),
+        grid_limits=tuple(tuple(float(x) for x in lim) for lim in back.grid_limits)
+        == tuple(tuple(float(x) for x in lim) for lim in limits),
+        indptr=bool(np.array_equal(back.indptr, geom.indptr) and back.indptr.dtype == geom.indptr.dtype),
+        gate_indices=bool(np.array_equal(back.gate_indices, geom.gate_indices)
+                          and back.gate_indices.dtype == geom.gate_indices.dtype),
+        weights=bool(np.array_equal(back.weights, geom.weights) and back.weights.dtype == geom.weights.dtype),
+        toa=float(back.toa) == 12000.0, radar_altitude=float(back.radar_altitude) == 312.5,
+        gridded_equal=bool(np.array_equal(grid_back, out["grid_DBZH"], equal_nan=True)))
+    blob = dict(grid_DBZH=out["grid_DBZH"], indptr=geom.indptr, gate_indices=geom.gate_indices, weights=geom.weights)
+    blob["meta"] = meta_blob(case="G8", volume=dict(n_elev=12, n_az=360, n_gates=1000, seed=8), digest=vol.digest(),
+                             grid_shape=shape, grid_limits=limits, weighting="barnes2", toa=12000.0,
+                             radar_altitude=312.5, fields=["DBZH"],
+                             reference_read_our_file=same, ref_file_keys=ref_keys, our_file_keys=our_keys,
+                             ref_file_dtypes=ref_dtypes, our_file_dtypes=our_dtypes,
+                             digests=dict(indptr=_sha(geom.indptr), gate_indices=_sha(geom.gate_indices),
+                                          weights=_sha(geom.weights)))
+    np.savez_compressed(os.path.join(HERE, "g8_interchange.npz"), **blob)
+    print("g8", same, ref_keys == our_keys)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None)
     args = ap.parse_args()
     ref = load_reference()
     from radar_processor_amd import synthetic as synth
-    gens = dict(g2=gen_g2, g3=gen_g3, g4=gen_g4, g5=gen_g5, g6=gen_g6, g7=gen_g7)
+    gens = dict(g2=gen_g2, g3=gen_g3, g4=gen_g4, g5=gen_g5, g6=gen_g6, g7=gen_g7, g8=gen_g8)
     for name, fn in gens.items():
         if args.only and name not in args.only:
             continue

@@ -290,3 +290,178 @@ def test_c2_pipeline_graph_with_compact_copy(c2):
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a,
                            b.view(torch.int32) if b.dtype == torch.float32 else b)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The METRIC workload itself (BASELINE.json's metric; bench.py's default): 12x360x1000 gates -> 40x2000x2000,
+# 8.3 G CSR pairs -- the only configuration with a REAL int64 indptr and pair offsets beyond 2^31.
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def metric(tmp_path_factory):
+    import torch
+    import radar_processor_amd as rg
+    from radar_processor_amd import synthetic
+    rg.load_library()
+    cfg = synthetic.CONFIGS["METRIC"]
+    vol = synthetic.make_volume(cfg["n_elev"], cfg["n_az"], cfg["n_gates"], seed=0, fields=("DBZH",))
+    dev = torch.device("cuda", 0)
+    torch.cuda.empty_cache()
+    geom = rg.compute_grid_geometry(vol.gate_x, vol.gate_y, vol.gate_z, cfg["grid_shape"], cfg["grid_limits"],
+                                    str(tmp_path_factory.mktemp("geom_metric")))
+    to = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dtype=dt)
+    f = to(np.ma.getdata(vol.fields["DBZH"]), torch.float32)
+    m = to(np.ma.getmaskarray(vol.fields["DBZH"]), torch.uint8)
+    ctx = dict(rg=rg, torch=torch, cfg=cfg, vol=vol, geom=geom, dev=dev, f=f, m=m)
+    yield ctx
+    ctx.clear()
+    del geom, f, m
+    torch.cuda.empty_cache()
+
+
+def _metric_grids(metric):
+    """K1 (reference-format CSR) and K1c (compact copy) grids of DBZH, computed once per module."""
+    if "k1" not in metric:
+        from radar_processor_amd.gridding import CsrGridder
+        torch, geom, dev, f, m = metric["torch"], metric["geom"], metric["dev"], metric["f"], metric["m"]
+        g_s = CsrGridder(geom, f.numel(), 1, device=dev)
+        g_c = CsrGridder(geom, f.numel(), 1, device=dev, compact=True)
+        assert g_s.compact is None and g_c.compact is not None
+        g_s.pack([f], [m]); g_c.pack([f], [m])
+        k1 = torch.empty((1, g_s.n_vox), dtype=torch.float32, device=dev)
+        k1c = torch.full_like(k1, -7.0)
+        g_s.apply(k1); g_c.apply(k1c)
+        torch.cuda.synchronize()
+        metric["k1"], metric["k1c"], metric["g_c"] = k1, k1c, g_c
+    return metric["k1"], metric["k1c"]
+
+
+def test_metric_int64_csr_structure(metric):
+    torch, geom, dev, cfg = metric["torch"], metric["geom"], metric["dev"], metric["cfg"]
+    csr = geom.device_csr(dev)
+    n_vox = int(np.prod(cfg["grid_shape"]))
+    assert csr.n_vox == n_vox == 160_000_000
+    assert csr.is_i64 and csr.indptr.dtype == torch.int64        # the reference's int32 indptr overflows here (F6)
+    assert csr.n_pairs > 2 ** 32 and csr.n_pairs == csr.weights.numel() == csr.gate_indices.numel()
+    ip = csr.indptr
+    assert int(ip[0]) == 0 and int(ip[-1]) == csr.n_pairs
+    lengths = ip[1:] - ip[:-1]
+    assert int(lengths.min()) >= 0 and int(lengths.max()) < 4096          # monotone, sane row lengths
+    first_big = int(torch.searchsorted(ip, torch.tensor([2 ** 31], device=dev, dtype=torch.int64))[0])
+    assert 0 < first_big < n_vox // 2                                      # most of the grid lies beyond offset 2^31
+    del lengths
+    assert int(csr.gate_indices.min()) >= 0 and csr.max_gate < metric["vol"].n_total_gates
+    assert int(csr.gate_indices.max()) == csr.max_gate
+    w = csr.weights
+    assert float(w.min()) >= np.float32(np.exp(-4.0) + 1e-5) * (1 - 1e-6) and float(w.max()) <= 1.00002
+
+
+def test_metric_compact_equals_reference_format_bit_for_bit(metric):
+    """K1c (what bench.py times) == K1 (the reference's CSR format) on the full 8.3 G-pair geometry, bit for bit;
+    a constant field grids to the constant; the decoded compact copy reproduces gate_indices beyond offset 2^31."""
+    torch, geom, dev = metric["torch"], metric["geom"], metric["dev"]
+    k1, k1c = _metric_grids(metric)
+    assert bool(torch.equal(k1.view(torch.int32), k1c.view(torch.int32)))
+    csr = geom.device_csr(dev)
+    filled = torch.isfinite(k1[0])
+    assert 0.55 < float(filled.float().mean()) < 0.8
+    assert bool((filled <= ((csr.indptr[1:] - csr.indptr[:-1]) > 0)).all())     # filled => row non-empty
+    g_c = metric["g_c"]
+    const = torch.full_like(metric["f"], -12.5)
+    g_c.pack([const], [None])
+    out = torch.empty_like(k1c)
+    g_c.apply(out)
+    nonempty = (csr.indptr[1:] - csr.indptr[:-1]) > 0
+    assert bool((torch.isfinite(out[0]) == nonempty).all())
+    assert float((out[0][nonempty] + 12.5).abs().max()) <= 12.5 * 2e-6
+    del out, nonempty, filled
+    compact = geom.device_compact(dev)
+    nz, ny, nx = metric["cfg"]["grid_shape"]
+    for r0, r1 in (((25 * ny + 1000) * nx + 3, (25 * ny + 1003) * nx + 1777), (csr.n_vox - 3 * nx - 5, csr.n_vox)):
+        p0, p1 = int(csr.indptr[r0]), int(csr.indptr[r1])
+        assert p0 > 2 ** 31
+        assert torch.equal(compact.decode(csr, r0, r1), csr.gate_indices[p0:p1])
+
+
+def test_metric_oracle_rows_beyond_2_31(metric):
+    """oracle.csr_apply (the restatement of interpolate.py:69-104) on whole y-rows of the full-size CSR whose pair
+    offsets lie beyond 2^31 -- including the first row past 2^31, the last row of the grid (last chunk) -- and the
+    builder's neighbour sets there against the brute-force oracle (compute.py:46-91)."""
+    torch, geom, dev, vol, cfg = metric["torch"], metric["geom"], metric["dev"], metric["vol"], metric["cfg"]
+    k1, k1c = _metric_grids(metric)
+    csr = geom.device_csr(dev)
+    nz, ny, nx = cfg["grid_shape"]
+    limits = cfg["grid_limits"]
+    data, mask = oracle.merge_masks(vol.fields["DBZH"])
+    ip_rows = csr.indptr[::nx].cpu().numpy()
+    first = int(np.searchsorted(ip_rows, 2 ** 31))                 # first (z,y) row that starts beyond 2^31
+    rows = [first, first + 1, (20 * ny + 1000), (30 * ny + 777), (37 * ny + 1500), nz * ny - 1]
+    scale = float(np.abs(data[np.isfinite(data) & ~mask]).max())
+    xc = np.linspace(limits[2][0], limits[2][1], nx, dtype="float32")
+    yc = np.linspace(limits[1][0], limits[1][1], ny, dtype="float32")
+    zc = np.linspace(limits[0][0], limits[0][1], nz, dtype="float32")
+    checked_pairs = 0
+    for r in rows:
+        iz, iy = divmod(r, ny)
+        v0 = r * nx
+        ip = csr.indptr[v0:v0 + nx + 1].cpu().numpy()
+        assert ip[0] >= 2 ** 31
+        idx = csr.gate_indices[int(ip[0]):int(ip[-1])].cpu().numpy()
+        w = csr.weights[int(ip[0]):int(ip[-1])].cpu().numpy()
+        want = oracle.csr_apply(ip - ip[0], idx, w, data, mask, (1, 1, nx))[0, 0]
+        for got_t in (k1, k1c):
+            got = got_t[0, v0:v0 + nx].cpu().numpy()
+            np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+            np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5 * scale, equal_nan=True)
+        checked_pairs += int(ip[-1] - ip[0])
+        for ix0 in (37, 1000, 1960):
+            sub = ((float(zc[iz]), float(zc[iz])), (float(yc[iy]), float(yc[iy])), (float(xc[ix0]), float(xc[ix0 + 3])))
+            o_ip, o_idx, o_w = oracle.build_geometry(vol.gate_x, vol.gate_y, vol.gate_z, (1, 1, 4), sub)
+            for k in (0, 3):   # the end points of a 4-point linspace are the grid's own float32 coordinates
+                s_ref = o_idx[o_ip[k]:o_ip[k + 1]]
+                lo, hi = int(ip[ix0 + k] - ip[0]), int(ip[ix0 + k + 1] - ip[0])
+                order = np.argsort(idx[lo:hi], kind="stable")
+                np.testing.assert_array_equal(idx[lo:hi][order], s_ref)
+                w_ref = o_w[o_ip[k]:o_ip[k + 1]]
+                ulp = np.abs(w[lo:hi][order].view(np.int32).astype(np.int64) - w_ref.view(np.int32).astype(np.int64))
+                assert ulp.max(initial=0) <= 1
+    assert checked_pairs > 100_000
+
+
+def test_metric_fused_gridder_and_products(metric):
+    """K2 (no CSR) against K1 on the full metric grid: identical NaN pattern, values within 1e-5 * max|field|;
+    COLMAX / argmax / CAPPI consistency on the 40-level grid."""
+    rg, torch, geom, dev, vol, cfg = (metric[k] for k in ("rg", "torch", "geom", "dev", "vol", "cfg"))
+    k1, _ = _metric_grids(metric)
+    nz, ny, nx = cfg["grid_shape"]
+    search = rg.RoiSearch(vol.gate_x, vol.gate_y, vol.gate_z, cfg["grid_shape"], cfg["grid_limits"])
+    k2 = rg.roi_grid_fields_device(search, [metric["f"]], [metric["m"]])
+    del search
+    grid = k1.view(1, nz, ny, nx)
+    assert bool((torch.isnan(grid) == torch.isnan(k2)).all())
+    scale = float(torch.nan_to_num(metric["f"], nan=0.0).abs().max())
+    assert float(torch.nan_to_num(grid - k2, nan=0.0).abs().max()) <= 1e-5 * scale
+    del k2
+    grid = grid[0]
+    cmax, arg = rg.column_argmax(grid)
+    has = arg >= 0
+    assert bool((has == torch.isfinite(cmax)).all())
+    picked = torch.gather(grid, 0, arg.clamp(min=0).long().unsqueeze(0))[0]
+    assert bool((picked[has] == cmax[has]).all())
+    for iz in range(nz):                                # level by level: no 160 M-element temporaries
+        lvl = grid[iz]
+        fin = torch.isfinite(lvl)
+        assert bool((lvl[fin] <= cmax[fin]).all())
+        assert not bool(((lvl == cmax) & (arg > iz)).any())          # first-index tie rule
+    cap = rg.constant_altitude_ppi(grid, geom, 4000.0)               # z 0..15 km over 40 levels: 4000 m is a lerp
+    plan = oracle.cappi_plan(cfg["grid_limits"][0], nz, 4000.0)
+    assert plan[0] == "lerp"
+    lo, hi = grid[plan[1]], grid[plan[1] + 1]
+    both = torch.isfinite(lo) & torch.isfinite(hi)
+    assert bool((torch.isfinite(cap) == both).all())
+    for iy in (0, 1000, 1999):                                       # oracle on whole y-rows, bit for bit
+        rows = grid[:, iy, :].cpu().numpy()[:, None, :]
+        np.testing.assert_array_equal(cap[iy].cpu().numpy(), oracle.cappi(rows, cfg["grid_limits"][0], 4000.0)[0])
+        np.testing.assert_array_equal(cmax[iy].cpu().numpy(), oracle.column_max(rows, 0, nz - 1)[0])
+        np.testing.assert_array_equal(arg[iy].cpu().numpy(), oracle.column_argmax(rows, 0, nz - 1)[0])
+    assert bool((cap[both] >= torch.minimum(lo, hi)[both] - 1e-4).all())
+    assert bool((cap[both] <= torch.maximum(lo, hi)[both] + 1e-4).all())

@@ -4,8 +4,10 @@
  * the CPU oracle on the same seeded inputs,
 
 at sizes the oracle finishes in seconds.  Bars: neighbour sets / indices bit-exact; Barnes weights within 1
-float32 ulp; gridded values rtol 1e-5 with an absolute floor of 1e-5 * max|field| (the reference sums in
-float32, the GPU in float64 -- SURVEY.md §7 "Summation order"); products bit-exact.
+float32 ulp; gridded values rtol 1e-5 with an absolute floor of 1e-5 * max|field| (both sides sum float32 products in
+float32 but in different orders -- NumPy's reduceat vs the kernel's tile/lane order -- so a weighted mean of mixed-sign
+data that cancels to nearly zero has no relative floor; test_reference_grid_relative_error measures how often the floor
+is needed and asserts the pure relative bar wherever |want| > 1e-3 * max|field|); products bit-exact.
 """
 import numpy as np
 import pytest
@@ -142,6 +144,48 @@ def test_apply_geometry_matches_reference(rg, name):
             data, mask = oracle.merge_masks(vol.fields[fname])
             key = f"grid_{fname}_qc" if (gf is not None and i == 0) else f"grid_{fname}"
             _assert_grid_close(multi[fname], ref[key], _atol(data, mask))
+
+
+def test_reference_grid_relative_error(rg):
+    """north_star's bar is "<= 1e-5 relative fp32".  Both sides multiply and sum in float32 but in different orders, so
+    the comparison above carries an absolute floor (1e-5 * max|field|) for weighted means that cancel to ~0.  This test
+    justifies it: over every reference fixture grid, per field, it measures the worst RELATIVE error on the voxels whose
+    magnitude is above 1e-3 * max|field| and asserts <= 1e-5 there with NO absolute term, and it counts the voxels of
+    the whole grid that only pass thanks to the floor.  The numbers are written to gpurun_out/parity_relerr.json."""
+    import json
+    import os
+    worst = {}
+    total = dict(voxels=0, significant=0, needed_floor=0)
+    for name in golden_names("g2_") + golden_names("g3_") + golden_names("g6_"):
+        meta, ref = load_golden(name)
+        vol = volume_for(meta)
+        geom = _ref_geometry(rg, name, meta, ref)
+        radar = vol.as_radar()
+        for fname in meta["fields"]:
+            data, mask = oracle.merge_masks(vol.fields[fname])
+            scale = _atol(data, mask) / RTOL                    # max |field| over the unmasked finite gates
+            got = rg.apply_geometry(geom, rg.get_field_data(radar, fname))
+            want = ref[f"grid_{fname}"]
+            filled = np.isfinite(want)
+            np.testing.assert_array_equal(np.isfinite(got), filled)
+            err = np.abs(got[filled].astype(np.float64) - want[filled].astype(np.float64))
+            mag = np.abs(want[filled].astype(np.float64))
+            sig = mag > 1e-3 * scale
+            rel = float((err[sig] / mag[sig]).max()) if sig.any() else 0.0
+            needed = int((err > RTOL * mag).sum())              # voxels that would fail a purely relative comparison
+            rec = worst.setdefault(fname, dict(max_rel_significant=0.0, needed_floor=0, voxels=0, max_abs_over_scale=0.0))
+            rec["max_rel_significant"] = max(rec["max_rel_significant"], rel)
+            rec["needed_floor"] += needed
+            rec["voxels"] += int(filled.sum())
+            rec["max_abs_over_scale"] = max(rec["max_abs_over_scale"], float(err.max() / scale) if err.size else 0.0)
+            total["voxels"] += int(filled.sum()); total["significant"] += int(sig.sum()); total["needed_floor"] += needed
+            assert rel <= RTOL, (name, fname, rel)              # no absolute floor here
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "parity_relerr.json"), "w") as fh:
+        json.dump(dict(per_field=worst, total=total), fh, indent=1)
+    print("parity_relerr", json.dumps(dict(per_field=worst, total=total)))
+    # the floor is a rarity, not a crutch: at most one filled voxel in a thousand needs it
+    assert total["needed_floor"] <= 1e-3 * total["voxels"], total
 
 
 @pytest.mark.parametrize("n_fields", [1, 2, 3, 4, 5, 8, 11])
@@ -312,18 +356,58 @@ def test_device_gate_predicates(rg):
     np.testing.assert_array_equal(m, (data < 0) | ~np.isfinite(data))
 
 
-def test_antenna_transform_kernel(rg):
+def test_antenna_transform_kernel_vs_oracle_parity_unpinned(rg):
+    """a1: ``rg_antenna_to_cartesian_f32`` against ``oracle.antenna_to_cartesian`` -- the oracle's restatement of the
+    published 4/3-earth model -- directly, not against the package's own host code.  **Parity unpinned** against the
+    reference's actual transform: that is PyART's ``antenna_vectors_to_cartesian`` (arm-pyart >= 2.1.1, call sites
+    src/radar_grid/utils.py:35-37), absent from /root/reference and from this image, and no reference test pins a
+    gate coordinate.  The package's host generator (`synthetic.gate_coordinates`) is checked against both as well."""
     from radar_processor_amd import synthetic
     elev, az, rng_m = synthetic.sweep_geometry(12, 90, 333)
     x, y, z = synthetic.gate_coordinates_device(elev, az, rng_m)
-    ex, ey, ez = synthetic.gate_coordinates(elev, az, rng_m)
-    for got, want in ((x, ex), (y, ey), (z, ez)):
+    el3 = np.asarray(elev)[:, None, None]
+    az3 = np.asarray(az)[None, :, None]
+    r3 = np.asarray(rng_m)[None, None, :]
+    shape = (len(elev), len(az), len(rng_m))
+    want64 = oracle.antenna_to_cartesian(r3, az3, el3)
+    want = [np.broadcast_to(c, shape).astype(np.float32).ravel() for c in want64]
+    host = synthetic.gate_coordinates(elev, az, rng_m)
+    for got, w, h in zip((x, y, z), want, host):
         got = got.cpu().numpy()
-        ulp = np.abs(got.view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64))
-        # float64 sin/cos/asin of two libms rounded to float32: identical except rare 1-ulp double roundings
-        close_to_zero = np.abs(want) < 1e-3
-        assert ulp[~close_to_zero].max() <= 1
-        np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-3)
+        assert got.shape == w.shape
+        for other in (w, h):
+            ulp = np.abs(got.view(np.int32).astype(np.int64) - other.view(np.int32).astype(np.int64))
+            # float64 sin/cos/asin/sqrt of two libms rounded to float32: identical except rare 1-ulp double roundings;
+            # coordinates that cancel to ~0 (x at azimuth 0/180, y at 90/270) have no relative scale
+            close_to_zero = np.abs(other) < 1e-3
+            assert ulp[~close_to_zero].max() <= 1
+            np.testing.assert_allclose(got, other, rtol=1e-6, atol=1e-3)
+
+
+def test_reference_written_npz_grids_on_gpu(rg):
+    """geometry.py:121-150: the `.npz` the REFERENCE's save_geometry wrote (tests/golden/g8_ref_saved_geometry.npz)
+    loaded by this build's load_geometry and gridded by the HIP path, against the grid the reference computed."""
+    import os
+    from conftest import GOLDEN
+    meta, ref = load_golden("g8_interchange")
+    vol = volume_for(meta)
+    geom = rg.load_geometry(os.path.join(GOLDEN, "g8_ref_saved_geometry.npz"))
+    got = rg.apply_geometry(geom, vol.fields["DBZH"])
+    data, mask = oracle.merge_masks(vol.fields["DBZH"])
+    _assert_grid_close(got, ref["grid_DBZH"], _atol(data, mask))
+    # and the file this build writes from a device-built geometry of the same window holds the same neighbour sets
+    import tempfile
+    shape, limits = grid_spec(meta)
+    with tempfile.TemporaryDirectory() as tmp:
+        built = rg.compute_grid_geometry(vol.gate_x, vol.gate_y, vol.gate_z, shape, limits, tmp, toa=meta["toa"])
+        path = os.path.join(tmp, "built.npz")
+        rg.save_geometry(built, path)
+        back = rg.load_geometry(path)
+    ip, idx, _ = oracle.canonical_rows(back.indptr, back.gate_indices, back.weights)
+    rip, ridx, _ = oracle.canonical_rows(ref["indptr"], ref["gate_indices"], ref["weights"])
+    np.testing.assert_array_equal(ip, rip)
+    np.testing.assert_array_equal(idx, ridx)
+    assert back.indptr.dtype == ref["indptr"].dtype and back.gate_indices.dtype == ref["gate_indices"].dtype
 
 
 # ------------------------------------------------------------------------------------------------

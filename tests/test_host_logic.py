@@ -81,6 +81,44 @@ class TestGridGeometry:           # reference: tests/test_radar_grid_geometry.py
         assert g.toa == np.inf and g.radar_altitude == 0.0 and g.n_pairs() == 2
 
 
+class TestNpzInterchangeWithTheReference:
+    """geometry.py:94-150 both ways, pinned by tests/golden/make_golden.py::gen_g8 (run in the build container, where
+    the reference is importable): a file written by the REFERENCE's save_geometry is read by this build, and the
+    reference read a file written by this build (outcome recorded in the fixture)."""
+
+    def test_reference_written_file_loads(self, tmp_path):
+        import hashlib
+        from conftest import GOLDEN, load_golden
+        meta, arr = load_golden("g8_interchange")
+        geom = rg.load_geometry(os.path.join(GOLDEN, "g8_ref_saved_geometry.npz"))
+        assert tuple(int(v) for v in geom.grid_shape) == tuple(meta["grid_shape"])
+        assert tuple(tuple(float(x) for x in lim) for lim in geom.grid_limits) == \
+            tuple(tuple(float(x) for x in lim) for lim in meta["grid_limits"])
+        assert geom.toa == meta["toa"] and geom.radar_altitude == meta["radar_altitude"]
+        for name in ("indptr", "gate_indices", "weights"):
+            got = getattr(geom, name)
+            assert got.dtype == arr[name].dtype and np.array_equal(got, arr[name]), name
+            digest = hashlib.sha256(np.ascontiguousarray(got).tobytes()).hexdigest()
+            assert meta["digests"][name].startswith(digest + ":"), name
+        assert geom.n_pairs() == len(arr["gate_indices"]) and geom.indptr.dtype == np.int32
+        # re-saving what we loaded reproduces the reference file's keys, dtypes and contents
+        path = str(tmp_path / "resaved.npz")
+        rg.save_geometry(geom, path)
+        with np.load(path) as ours, np.load(os.path.join(GOLDEN, "g8_ref_saved_geometry.npz")) as theirs:
+            assert sorted(ours.files) == sorted(theirs.files) == meta["ref_file_keys"]
+            for k in theirs.files:
+                assert ours[k].dtype == theirs[k].dtype and ours[k].shape == theirs[k].shape, k
+                assert np.array_equal(ours[k], theirs[k]), k
+
+    def test_reference_read_our_file(self):
+        from conftest import load_golden
+        meta, _ = load_golden("g8_interchange")
+        outcome = meta["reference_read_our_file"]
+        assert outcome and all(outcome.values()), outcome       # every field equal, and the reference gridded the same bits
+        assert meta["ref_file_keys"] == meta["our_file_keys"]
+        assert meta["ref_file_dtypes"] == meta["our_file_dtypes"]
+
+
 @pytest.fixture
 def radar():
     rng = np.random.default_rng(0)
@@ -270,3 +308,27 @@ class TestNativeLibrary:
                 if f.endswith(".py"):
                     text = open(os.path.join(root, f)).read()
                     assert not re.search(r"^\s*(from|import)\s+oracle", text, flags=re.M), f"{f} imports the oracle"
+
+
+class TestBenchLauncher:
+    """bench.py --gpus N: never a smaller run labelled N.  CPU-only checks of the refusals; the
+    launches themselves are covered on the GPU box (tests/test_gpu_batch.py)."""
+
+    def _run(self, args, env_extra):
+        import subprocess
+        import sys
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+        env.update(env_extra)
+        return subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), *args], capture_output=True, env=env,
+                              timeout=300, cwd=REPO)
+
+    def test_world_size_must_match_gpus(self):
+        res = self._run(["--gpus", "4"], dict(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"))
+        assert res.returncode == 2 and b"WORLD_SIZE=1 but --gpus 4" in res.stderr and not res.stdout.strip()
+
+    def test_parent_refuses_more_ranks_than_gpus(self):
+        import torch
+        if torch.cuda.device_count() >= 8:
+            pytest.skip("box has 8 GPUs")
+        res = self._run(["--gpus", "8"], {})
+        assert res.returncode == 2 and b"refusing to label a smaller run" in res.stderr and not res.stdout.strip()
