@@ -375,10 +375,10 @@ def run_rank(args):
     if args.mode == "csr":
         import tempfile
         with tempfile.TemporaryDirectory() as tmp:
-            # single-field passes use the compact copy of the CSR; 'auto' keeps the reference's index array next to it
-            # when both fit and builds the copy alone otherwise (config 4: 33 G pairs)
-            fields_per_pass = min(8, n_ff)     # C5: VolumeBatch fuses up to 8 field-volumes into one pass
-            want_compact = fields_per_pass == 1 and not args.no_compact
+            # passes run through the compact copy of the CSR; 'auto' keeps the reference's index array next to it when
+            # both fit and builds the copy alone otherwise (config 4: 33 G pairs)
+            fields_per_pass = min(4 if c5 else 8, n_ff)     # C5: VolumeBatch fuses up to 4 field-volumes into one CSR pass
+            want_compact = not args.no_compact
             geom = rg.compute_grid_geometry(vol.gate_x, vol.gate_y, vol.gate_z, shape, limits, tmp,
                                             layout="auto" if want_compact else "csr")
         if want_compact and geom.device_csr(dev).gate_indices is not None:

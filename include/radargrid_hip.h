@@ -108,15 +108,19 @@ int rg_pack_fields_f32(int32_t n_fields, const float* const* fields_host, const 
  * the gather goes through a range-checked buffer resource of n_gates * stride * 4 bytes (which must stay below
  * 4 GiB): a gate index outside [0, n_gates) reads as 0.0 and cannot fault the GPU.
  * indptr must be non-decreasing with indptr[0] = 0 and indptr[n_vox] = n_pairs.
+ * line_len: rows per grid line (nx of an nz x ny x nx grid; n_vox must be a multiple of it; <= 0 = one line of n_vox
+ * rows).  A wavefront owns a segment of up to 64 consecutive rows of ONE line (a line is cut into ceil(line_len / 64)
+ * balanced segments); the value only changes which rows share a wavefront -- hence the order of the float32 adds --
+ * never which pairs are summed.
  * ------------------------------------------------------------------------------------------------- */
 int rg_csr_apply_f32(const void* indptr, int32_t indptr_is_i64, const int32_t* gate_idx, const float* weights,
-                     int64_t n_vox, int64_t n_pairs,
+                     int64_t n_vox, int64_t n_pairs, int64_t line_len,
                      const float* packed, int32_t n_fields, int32_t stride, int64_t n_gates,
                      float fill_value, float* out, rg_stream_t stream);
 /* diagnostic: same kernel with a tuning variant (tile size, waves per workgroup, pipeline depth, placement) selected explicitly;
  * variant 0 is what rg_csr_apply_f32 runs.  Used only by tools/tune_k1.py for A/B timing in one process. */
 int rg_csr_apply_f32_ex(const void* indptr, int32_t indptr_is_i64, const int32_t* gate_idx, const float* weights,
-                        int64_t n_vox, int64_t n_pairs,
+                        int64_t n_vox, int64_t n_pairs, int64_t line_len,
                         const float* packed, int32_t n_fields, int32_t stride, int64_t n_gates,
                         float fill_value, float* out, int32_t variant, rg_stream_t stream);
 
@@ -294,34 +298,51 @@ int rg_grid_filter(const void* src, int32_t data_is_f64, int64_t n, int32_t flag
                    const uint8_t* mask, double fill_value, void* out, rg_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
- * K1c  csr_apply over a compact device copy of the CSR -- same results as rg_csr_apply_f32 for one field, bit for
- * bit, from 6 instead of 8 streamed bytes per pair and one gather per DISTINCT gate of a chunk instead of one per
- * pair.  Rows are grouped in chunks of RG_COMPACT_ROWS consecutive voxels; chunk c lists its distinct gate indices
- * in dict[dict_ptr[c] .. dict_ptr[c+1]) (at most 65536 of them, any order) and pair p of one of its rows stores
- * local_idx[p] = position of its gate in that list.  indptr and weights are those of the standard CSR
+ * K1c  csr_apply over a compact device copy of the CSR -- same results as rg_csr_apply_f32 for every field count,
+ * bit for bit, from 6 instead of 8 streamed bytes per pair and one gather per DISTINCT gate of a chunk instead of one
+ * per pair.  The grid is planes x lines x rows (n_vox = n_planes * lines_per_plane * line_len; nz x ny x nx for a radar
+ * grid).  A chunk is a 2-D patch: segment sx (one of the ceil(line_len / 64) balanced pieces of a line, the unit one
+ * wavefront of rg_csr_apply_f32 owns) of the RG_COMPACT_LINES consecutive lines yg*RG_COMPACT_LINES.. of one plane; chunks are
+ * numbered c = (plane * ceil(lines_per_plane / RG_COMPACT_LINES) + yg) * ceil(line_len / 64) + sx.  Chunk c lists its
+ * distinct gate indices in dict[dict_ptr[c] .. dict_ptr[c+1]) (at most 65536 of them, any order) and pair p of one of
+ * its rows stores local_idx[p] = position of its gate in that list.  A chunk with MORE distinct gates is stored split:
+ * dict[dict_ptr[c] + w], w < RG_COMPACT_LINES, is the offset (from dict_ptr[c]) of a dictionary of its own for line w's
+ * segment, and positions refer to that; such a chunk is recognised by dict_ptr[c+1] - dict_ptr[c] > 65536.
+ * indptr and weights are those of the standard CSR
  * (radar_grid/geometry.py:46-52), which stays the interchange format; the compact arrays are derived from it on the
- * device (radar_processor_amd/grid_geometry.py: CompactCSR).  `packed` is the stride-1 layout of rg_pack_fields_f32.
- * window_cap: how many dictionary values a workgroup keeps in LDS (<= RG_COMPACT_MAX_WINDOW); chunks with a longer
- * dictionary gather per pair from memory, so any value is correct and the choice only affects speed.
- * tile: pairs per pipeline step, 0 = default.
+ * device (radar_processor_amd/grid_geometry.py: CompactCSR).  `packed` / n_fields / stride: as rg_csr_apply_f32.
+ * window_cap: how many dictionary entries (of `stride` floats) a workgroup keeps in LDS (<= RG_COMPACT_MAX_WINDOW,
+ * clamped to what fits next to the kernel's own LDS); chunks with a longer dictionary gather per pair from memory, so
+ * any value is correct and the choice only affects speed.  tile: pairs per pipeline step, 0 = default (= the tile of
+ * rg_csr_apply_f32 for the same field count; other values change the order of the float32 adds).
+ * line_len <= 0 means one line of n_vox rows, lines_per_plane <= 0 one plane.
  * ------------------------------------------------------------------------------------------------- */
-#define RG_COMPACT_ROWS 256
+#define RG_COMPACT_LINES 4
 #define RG_COMPACT_MAX_WINDOW 8192
 int rg_csr_compact_apply_f32(const void* indptr, int32_t indptr_is_i64, const uint16_t* local_idx, const float* weights,
                              const int64_t* dict_ptr, const int32_t* dict, int64_t n_vox, int64_t n_pairs,
-                             const float* packed, int64_t n_gates, float fill_value, float* out, int32_t window_cap,
+                             int64_t line_len, int64_t lines_per_plane, const float* packed, int32_t n_fields,
+                             int32_t stride, int64_t n_gates, float fill_value, float* out, int32_t window_cap,
                              int32_t tile, rg_stream_t stream);
 
-/* Building the compact copy from a standard CSR (or from one slab of it: pass indptr + first_row and pointers shifted
- * accordingly; the row pointers hold absolute pair positions).  rg_csr_compact_count: chunk_counts[c] = distinct
- * gates of chunk c (65537 = more than the 16-bit positions can address: not compactable), chunk_rounds[c] = hashing
- * rounds the chunk needed (opaque, handed to the fill pass).  The caller turns the counts into dict_ptr
- * (rg_scan_counts_i64, chunk_counts needs one spare entry) and calls rg_csr_compact_fill, which writes
- * dict[dict_ptr[c] ..] and local_idx[p] for every pair.  Dictionary order is unspecified. */
+/* number of chunks of a grid of n_rows rows (negative rg_status when the sizes do not factor) */
+int64_t rg_csr_compact_chunks(int64_t n_rows, int64_t line_len, int64_t lines_per_plane);
+
+/* Building the compact copy from a standard CSR, or from a slab of whole planes of it: pass indptr + first row of the
+ * slab, n_rows of the slab, and gate_idx / local_idx pointers such that element p is ABSOLUTE pair p (the row pointers
+ * hold absolute pair positions).  rg_csr_compact_count: chunk_counts[c] = dictionary entries of chunk c (header
+ * included for a split chunk; >= 0x40000000 = a single segment references more than 65536 gates: not compactable),
+ * chunk_rounds[c] = hashing rounds the chunk needed and its split flag (opaque, handed to the fill pass).  The caller turns the counts into dict_ptr (rg_scan_counts_i64, chunk_counts needs one
+ * spare entry) and calls rg_csr_compact_fill, which writes dict[dict_ptr[c] ..] and local_idx[p] for every pair.
+ * Dictionary order is unspecified.  *error_flag (device int32, zeroed by the caller) becomes non-zero when the fill
+ * pass meets inputs that differ from what the count pass saw (gate_idx modified in between, wrong chunk_rounds):
+ * every table walk is bounded, so such a mismatch is reported instead of hanging the GPU. */
 int rg_csr_compact_count(const void* indptr, int32_t indptr_is_i64, const int32_t* gate_idx, int64_t n_rows,
-                         int32_t* chunk_counts, uint8_t* chunk_rounds, rg_stream_t stream);
+                         int64_t line_len, int64_t lines_per_plane, int32_t* chunk_counts, uint8_t* chunk_rounds,
+                         rg_stream_t stream);
 int rg_csr_compact_fill(const void* indptr, int32_t indptr_is_i64, const int32_t* gate_idx, int64_t n_rows,
-                        const int64_t* dict_ptr, const uint8_t* chunk_rounds, int32_t* dict, uint16_t* local_idx,
+                        int64_t line_len, int64_t lines_per_plane, const int64_t* dict_ptr,
+                        const uint8_t* chunk_rounds, int32_t* dict, uint16_t* local_idx, int32_t* error_flag,
                         rg_stream_t stream);
 
 #ifdef __cplusplus

@@ -25,7 +25,7 @@ RG_MAX_PLANE_TESTS = 12
 RG_TEST_LO, RG_TEST_HI, RG_TEST_LO_INCLUSIVE, RG_TEST_NONFINITE = 1, 2, 4, 8
 RG_MINMAX_WORKSPACE_BYTES = 32768
 RG_MAX_LUT = 4093
-RG_COMPACT_ROWS = 256
+RG_COMPACT_LINES = 4          # grid lines (= wavefronts) per chunk of the compact CSR copy
 RG_COMPACT_MAX_WINDOW = 8192
 
 
@@ -57,10 +57,10 @@ SIGNATURES = {
     "rg_gate_mask_f32": (c_int32, [c_void_p, c_int64, c_int32, c_float, c_float, c_void_p, c_void_p]),
     "rg_pack_fields_f32": (c_int32, [c_int32, POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_int64, c_int32,
                                      c_void_p, c_void_p]),
-    "rg_csr_apply_f32": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int32,
+    "rg_csr_apply_f32": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int32,
                                    c_int32, c_int64, c_float, c_void_p, c_void_p]),
-    "rg_csr_apply_f32_ex": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int32,
-                                      c_int32, c_int64, c_float, c_void_p, c_int32, c_void_p]),
+    "rg_csr_apply_f32_ex": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p,
+                                      c_int32, c_int32, c_int64, c_float, c_void_p, c_int32, c_void_p]),
     "rg_column_reduce_f32": (c_int32, [c_void_p, c_int32, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                        c_void_p]),
     "rg_cappi_lerp_f32": (c_int32, [c_void_p, c_int64, c_int32, c_float, c_float, c_void_p, c_void_p]),
@@ -73,10 +73,13 @@ SIGNATURES = {
     "rg_geom_count_f32": (c_int32, [c_void_p, c_void_p, POINTER(CellGrid), c_void_p, c_void_p, c_void_p, c_int32,
                                     c_int32, c_int32, c_double, c_double, c_void_p, c_void_p]),
     "rg_csr_compact_apply_f32": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
-                                           c_void_p, c_int64, c_float, c_void_p, c_int32, c_int32, c_void_p]),
-    "rg_csr_compact_count": (c_int32, [c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
-    "rg_csr_compact_fill": (c_int32, [c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
-                                      c_void_p]),
+                                           c_int64, c_int64, c_void_p, c_int32, c_int32, c_int64, c_float, c_void_p,
+                                           c_int32, c_int32, c_void_p]),
+    "rg_csr_compact_chunks": (c_int64, [c_int64, c_int64, c_int64]),
+    "rg_csr_compact_count": (c_int32, [c_void_p, c_int32, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p,
+                                       c_void_p]),
+    "rg_csr_compact_fill": (c_int32, [c_void_p, c_int32, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_void_p]),
     "rg_scan_workspace_bytes": (c_int64, [c_int64]),
     "rg_scan_counts_i64": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
     "rg_geom_fill_f32": (c_int32, [c_void_p, c_void_p, POINTER(CellGrid), c_void_p, c_void_p, c_void_p, c_int32,

@@ -124,7 +124,11 @@ class VolumeBatch:
         self.dev = geometry.dev if self.fused else (_native.device() if device is None else device)
         if not 1 <= len(self.field_names) <= _native.RG_MAX_FIELDS:
             raise ValueError("1..8 fields per volume")
-        self.volumes_per_pass = max(1, _native.RG_MAX_FIELDS // len(self.field_names))
+        # measured on the bench grid (ms per fused pass, rg_csr_apply_f32): 1 field-volume 13.1 (9.5 through the compact
+        # copy), 2: 14.9 (13.0), 3: 18.8, 4: 20.7, 8: 55.1 -- four field-volumes per pass is the sweet spot (5.2 ms
+        # each); the CSR-free gridder keeps gaining up to 8 because it shares the whole neighbour search
+        cap = _native.RG_MAX_FIELDS if self.fused else min(4, _native.RG_MAX_FIELDS)
+        self.volumes_per_pass = max(1, cap // len(self.field_names))
 
     def _to_dev(self, a, dtype):
         import torch

@@ -54,6 +54,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     """Compile every HIP source for gfx950 and link the shared library. Returns its path."""
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, "rg_common.hpp"), os.path.join(CSRC, "rg_roi_search.hpp"),
+               os.path.join(CSRC, "rg_row_phase.hpp"),
                os.path.join(INCLUDE, "radargrid_hip.h")]
     common = ["-std=c++17", "-O3", f"--offload-arch={ARCH}", "-fPIC",
               f"-I{INCLUDE}", f"-I{CSRC}", "-Wall", "-Wno-unused-result", *COMMON_FLAGS]

@@ -4,8 +4,11 @@
 // Roofline: HBM.  Algorithmic bytes per launch = 8*P (gate_idx + weight per pair) + sizeof(indptr)*(V+1)
 //           + F*(5*G + 4*V)   (SURVEY.md §8(d)); the field gather is served by L1 / L2 / Infinity Cache.
 //
-// Mapping: "CSR-stream" at wavefront granularity.  One wavefront = 64 consecutive voxel rows = one contiguous
-// pair range, walked in tiles of TILE pairs with a two-deep software pipeline:
+// Mapping: "CSR-stream" at wavefront granularity.  One wavefront = one SEGMENT = up to 64 consecutive voxel rows of one
+// grid line (a line = `line_len` consecutive rows = one (z, y) row of nx voxels; segments never straddle lines, so the
+// compact kernel of rg_csr_compact.hip can stack the segments of neighbouring lines into 2-D patches and still add
+// exactly the same numbers in the same order) = one contiguous pair range, walked in tiles of TILE pairs with a
+// two-deep software pipeline:
 //
 //   products(t)    lane l handles pair t + 64*it + l (lane-contiguous): masked float32 products
 //                  (w*v, w) of tile t go to the wave's private LDS tile -- its gathered values were requested
@@ -22,6 +25,7 @@
 // Empty rows cost nothing, long rows only lengthen their own lanes' loop; no workgroup barrier, no atomics, no
 // inter-wave communication, so results are bit-reproducible run to run.
 #include "rg_common.hpp"
+#include "rg_row_phase.hpp"
 
 // 8- and 16-byte buffer loads by intrinsic name: this compiler's __builtin_amdgcn_raw_buffer_load_b64 / _b128 return
 // the first dword in every element (seen in the generated code), the intrinsics themselves are fine.  Declared at
@@ -80,6 +84,10 @@ using f32x2 = float __attribute__((ext_vector_type(2)));
 //     arithmetic from the loop: a tile's resource is rebuilt in SGPRs (base + t, remaining bytes), the lane offset
 //     is the constant 4 * lane and the 8 loads of a tile differ only in the instruction's immediate offset;
 //   * a software pipeline unrolled by two (see the comment inside).
+// Segments a line's wavefronts are rotated by per line (see the kernel).  Measured on the bench grid (32 segments per
+// line, 4 wavefronts per workgroup): 0 -> 14.1 ms, 1 -> 12.6, 2 -> 13.3, 3 -> 12.9, 4 -> 14.0, 5 -> 13.0, 8 -> 18.0.
+constexpr unsigned kSegmentRotation = 1;
+
 using rsrc_t = __amdgpu_buffer_rsrc_t;
 constexpr int kRsrcRaw32 = 0x00020000;   // gfx9 buffer resource word 3: DATA_FORMAT = 32, untyped dword access
 
@@ -109,30 +117,41 @@ __device__ __forceinline__ void buffer_load_packed(rsrc_t r, unsigned gate, floa
 template <typename IndT, int NF, int STRIDE, int TILE, int XCD, int FLAGS>
 __global__ __launch_bounds__(64 * wpb_of(FLAGS)) void csr_apply_dyn_kernel(
     const IndT* __restrict__ indptr, const int32_t* __restrict__ gidx, const float* __restrict__ wts,
-    long n_vox, long n_pairs, const float* __restrict__ packed, unsigned last_gate, float fill,
-    float* __restrict__ out) {
+    long n_vox, long line_len, unsigned segs_per_line, unsigned n_segs, unsigned rot_step,
+    const float* __restrict__ packed, unsigned last_gate, float fill, float* __restrict__ out) {
   static_assert(TILE % 64 == 0, "a wave handles 64 pairs per step");
   constexpr int IT = TILE / 64;
   static_assert(IT * 256 <= 4096, "the tile's loads are told apart by a 12-bit immediate offset");
-  constexpr int kLgStride = STRIDE == 1 ? 0 : STRIDE == 2 ? 1 : STRIDE == 4 ? 2 : 3;
   constexpr int WPB = wpb_of(FLAGS);
   constexpr int NST = (FLAGS & kStages3) ? 3 : 2;   // tiles of CSR in flight per wavefront
-  __shared__ f32x2 tile_all[WPB][TILE * STRIDE];
+  __shared__ __attribute__((aligned(16))) float tile_all[WPB][TILE * rg::tile_floats(NF, STRIDE)];
   __shared__ f32x2 rowacc_all[WPB][64 * STRIDE];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  f32x2* tile = tile_all[wv];
+  float* tile = tile_all[wv];
   f32x2* rowacc = rowacc_all[wv];
 
   const unsigned blk = place_block<XCD>(blockIdx.x, gridDim.x);
-  const long r0 = ((long)blk * WPB + wv) * 64;
-  if (r0 >= n_vox) return;  // wave-uniform
+  // segment index: line-major, segs_per_line segments of <= 64 rows per line.  32-bit arithmetic: a 64-bit division
+  // costs a few hundred instructions per wavefront on this ISA.
+  const unsigned seg0 = blk * WPB + wv;
+  if (seg0 >= n_segs) return;  // wave-uniform
+  const unsigned line = seg0 / segs_per_line;
+  // rotate the segments of a line by rot_step per line: workgroups are dealt to the 8 XCDs round-robin, so with
+  // segs_per_line a multiple of 8*WPB every XCD would own a fixed x-slab of the grid for the whole launch -- the slabs'
+  // pair counts differ by 2x between the grid's edge and its centre, and the XCDs that finish early idle (speed only)
+  const unsigned rot = seg0 - line * segs_per_line + (line * rot_step) % segs_per_line;
+  const unsigned sx = rot >= segs_per_line ? rot - segs_per_line : rot;
+  // a line's segments are balanced: the first line_len % segs_per_line of them hold one row more than the others
+  const unsigned seg_base = (unsigned)(line_len / segs_per_line), seg_extra = (unsigned)(line_len % segs_per_line);
+  const long r0 = (long)line * line_len + (long)(sx * seg_base + (sx < seg_extra ? sx : seg_extra));
+  const int nrows = (int)(seg_base + (sx < seg_extra ? 1u : 0u));   // <= 64
   const long row = r0 + lane;
   const long seg_b = (long)indptr[r0];
-  const long seg_e = (long)indptr[r0 + 64 < n_vox ? r0 + 64 : n_vox];
+  const long seg_e = (long)indptr[r0 + nrows];
   const int span = (int)(seg_e - seg_b);
-  const int rs_o = (int)((long)indptr[row < n_vox ? row : n_vox] - seg_b);
-  const int re_o = (int)((long)indptr[row + 1 < n_vox ? row + 1 : n_vox] - seg_b);
+  const int rs_o = (int)((long)indptr[r0 + (lane < nrows ? lane : nrows)] - seg_b);
+  const int re_o = (int)((long)indptr[r0 + (lane + 1 < nrows ? lane + 1 : nrows)] - seg_b);
 #pragma unroll
   for (int f = 0; f < STRIDE; ++f) rowacc[lane * STRIDE + f] = (f32x2)(0.0f);
 
@@ -182,56 +201,16 @@ __global__ __launch_bounds__(64 * wpb_of(FLAGS)) void csr_apply_dyn_kernel(
     };
     auto step = [&](int t, Stage& cur, const Stage& nxt, const Values& val, Values& val_nxt) {
       gather(nxt, val_nxt);
-      // ---- products of tile t -> LDS ---------------------------------------------------------------
+      // ---- products of tile t -> LDS (layout and arithmetic: rg_row_phase.hpp) -----------------------------
 #pragma unroll
-      for (int it = 0; it < IT; ++it) {
-#pragma unroll
-        for (int f = 0; f < STRIDE; ++f) {  // padding slots hold the sentinel -> (0, 0)
-          const bool ok = f < NF && rg::f32_bits(val.v[it][f]) != RG_EXCLUDED_BITS;
-          f32x2 e;
-          e.x = ok ? cur.cw[it] * val.v[it][f] : 0.0f;
-          e.y = ok ? cur.cw[it] : 0.0f;
-          tile[(it * 64 + lane) * STRIDE + f] = e;
-        }
-      }
+      for (int it = 0; it < IT; ++it) rg::store_products<NF, STRIDE>(tile, TILE, it * 64 + lane, cur.cw[it], val.v[it]);
       stream(cur, t + NST * TILE);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-      // ---- dynamic row phase ---------------------------------------------------------------------------
-      const unsigned long long act = __ballot(re_o > rs_o && re_o > t && rs_o < t + TILE);
-      if (act != 0) {  // wave-uniform
-        const int ra = __builtin_ctzll(act), rb = 63 - __builtin_clzll(act);
-        const int nact = rb - ra + 1;
-        int lg = 31 - __builtin_clz(64 / nact);          // lanes per row = 2^lg <= 64 / rows
-        lg = lg < kLgStride ? kLgStride : lg;            // ... but at least one lane per field slot
-        const int rpr = 64 >> lg;                        // rows per round
-        const int rin = lane & ((1 << lg) - 1);
-        const int fslot = rin & (STRIDE - 1);
-        const int sub = rin >> kLgStride, nsub = 1 << (lg - kLgStride);
-        for (int rbase = ra; rbase <= rb; rbase += rpr) {
-          const int myrow = rbase + (lane >> lg);
-          const bool live = myrow <= rb;
-          const int qs = __shfl(rs_o, myrow & 63, 64);
-          const int qe = __shfl(re_o, myrow & 63, 64);
-          const int a = (qs > t ? qs : t) - t;
-          const int b = live ? (qe < t + TILE ? qe : t + TILE) - t : a;
-          f32x2 part0 = (f32x2)(0.0f), part1 = (f32x2)(0.0f);
-          int j = a + sub;
-          for (; j + nsub < b; j += 2 * nsub) {  // two elements per trip, two independent partial sums
-            part0 += tile[j * STRIDE + fslot];
-            part1 += tile[(j + nsub) * STRIDE + fslot];
-          }
-          if (j < b) part0 += tile[j * STRIDE + fslot];
-          f32x2 sum = part0 + part1;
-          for (int m = STRIDE; m < (1 << lg); m <<= 1) {  // fold the interleaved streams of one field slot
-            sum.x += __shfl_xor(sum.x, m, 64);
-            sum.y += __shfl_xor(sum.y, m, 64);
-          }
-          if (live && sub == 0) rowacc[myrow * STRIDE + fslot] += sum;  // one owner per (row, slot): plain RMW
-        }
-      }
+      // ---- dynamic row phase (shared with rg_csr_compact_apply_f32: same lane split, same float32 adds) --------
+      rg::row_phase<NF, STRIDE, TILE>(tile, rowacc, t, rs_o, re_o, lane);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -252,7 +231,7 @@ __global__ __launch_bounds__(64 * wpb_of(FLAGS)) void csr_apply_dyn_kernel(
   }
 
   // ---- epilogue: lane == row again; one coalesced 256-byte store per field ------------------------------
-  if (row < n_vox) {
+  if (lane < nrows) {
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
       const f32x2 s = rowacc[lane * STRIDE + f];
@@ -262,29 +241,38 @@ __global__ __launch_bounds__(64 * wpb_of(FLAGS)) void csr_apply_dyn_kernel(
 }
 
 template <typename IndT, int NF, int STRIDE, int TILE, int XCD, int FLAGS>
-int launch_dyn(const void* indptr, const int32_t* gidx, const float* wts, long n_vox, long n_pairs, const float* packed,
+int launch_dyn(const void* indptr, const int32_t* gidx, const float* wts, long n_vox, long line_len, const float* packed,
                long n_gates, float fill, float* out, hipStream_t s) {
   constexpr int WPB = wpb_of(FLAGS);
-  const long chunks = (n_vox + 63) / 64;
-  const long blocks = (chunks + WPB - 1) / WPB;
+  const long segs_per_line = (line_len + 63) / 64;
+  const long n_segs = (n_vox / line_len) * segs_per_line;
+  if (n_segs > 0xFFFFFFF0L) {
+    rg::set_error("rg_csr_apply_f32: %ld segments exceed one launch", n_segs);
+    return RG_EUNSUPPORTED;
+  }
+  const long blocks = (n_segs + WPB - 1) / WPB;
   hipLaunchKernelGGL((csr_apply_dyn_kernel<IndT, NF, STRIDE, TILE, XCD, FLAGS>), dim3((unsigned)blocks), dim3(64 * WPB),
-                     0, s, static_cast<const IndT*>(indptr), gidx, wts, n_vox, n_pairs, packed, (unsigned)(n_gates - 1),
-                     fill, out);
+                     0, s, static_cast<const IndT*>(indptr), gidx, wts, n_vox, line_len, (unsigned)segs_per_line,
+                     (unsigned)n_segs, kSegmentRotation, packed,
+                     (unsigned)(n_gates - 1), fill, out);
   return rg::check_launch("rg_csr_apply_f32");
 }
 
 template <typename IndT>
-int dispatch(int nf, int variant, const void* indptr, const int32_t* gidx, const float* wts, long n_vox, long n_pairs,
+int dispatch(int nf, int variant, const void* indptr, const int32_t* gidx, const float* wts, long n_vox, long line_len,
              const float* packed, long n_gates, float fill, float* out, hipStream_t s) {
 #define RG_KD(NF_, ST_, TILE_, XCD_, FLAGS_) \
-  launch_dyn<IndT, NF_, ST_, TILE_, XCD_, FLAGS_>(indptr, gidx, wts, n_vox, n_pairs, packed, n_gates, fill, out, s)
-  if (nf == 1) {  // tuning variants (tools/tune_k1.py) exist for the single-field kernel only; 0 = what ships
+  launch_dyn<IndT, NF_, ST_, TILE_, XCD_, FLAGS_>(indptr, gidx, wts, n_vox, line_len, packed, n_gates, fill, out, s)
+  // `variant`: 0 = what ships.  128/256/384/512 select the pipeline tile explicitly (A/B timing, and the bit-identity
+  // tests of rg_csr_compact_apply_f32 with a non-default tile); the other codes are single-field tuning variants
+  // (tools/tune_k1.py).
+  if (nf == 1) {
     switch (variant) {
       case 8: return RG_KD(1, 1, 512, kXcdSlab, 0);       // XCD placement
       case 16: return RG_KD(1, 1, 512, kXcdGroup, 0);
-      case 18: return RG_KD(1, 1, 256, kXcdNone, 0);      // tile size
+      case 256: case 18: return RG_KD(1, 1, 256, kXcdNone, 0);      // tile size
       case 23: return RG_KD(1, 1, 448, kXcdNone, 0);
-      case 9: return RG_KD(1, 1, 512, kXcdNone, 0);
+      case 512: case 9: return RG_KD(1, 1, 512, kXcdNone, 0);
       case 17: return RG_KD(1, 1, 640, kXcdNone, 0);
       case 19: return RG_KD(1, 1, 512, kXcdNone, kWpb1);  // waves per workgroup
       case 20: return RG_KD(1, 1, 512, kXcdNone, kWpb2);
@@ -297,9 +285,23 @@ int dispatch(int nf, int variant, const void* indptr, const int32_t* gidx, const
     }
   }
   switch (nf) {
-    case 2: return RG_KD(2, 2, 512, kXcdNone, 0);
-    case 3: return RG_KD(3, 4, 256, kXcdNone, 0);
-    case 4: return RG_KD(4, 4, 256, kXcdNone, 0);
+    case 2:
+      switch (variant) {
+        case 128: return RG_KD(2, 2, 128, kXcdNone, 0);
+        case 512: return RG_KD(2, 2, 512, kXcdNone, 0);
+        default: return RG_KD(2, 2, 256, kXcdNone, 0);
+      }
+    case 3:
+      switch (variant) {
+        case 128: return RG_KD(3, 4, 128, kXcdNone, 0);
+        case 384: return RG_KD(3, 4, 384, kXcdNone, 0);
+        default: return RG_KD(3, 4, 256, kXcdNone, 0);
+      }
+    case 4:
+      switch (variant) {
+        case 128: return RG_KD(4, 4, 128, kXcdNone, 0);
+        default: return RG_KD(4, 4, 256, kXcdNone, 0);
+      }
     case 5: return RG_KD(5, 8, 128, kXcdNone, 0);
     case 6: return RG_KD(6, 8, 128, kXcdNone, 0);
     case 7: return RG_KD(7, 8, 128, kXcdNone, 0);
@@ -313,9 +315,9 @@ inline int stride_for(int nf) { return nf == 1 ? 1 : nf == 2 ? 2 : nf <= 4 ? 4 :
 }  // namespace
 
 extern "C" int rg_csr_apply_f32_ex(const void* indptr, int32_t indptr_is_i64, const int32_t* gate_idx,
-                                   const float* weights, int64_t n_vox, int64_t n_pairs, const float* packed,
-                                   int32_t n_fields, int32_t stride, int64_t n_gates, float fill_value, float* out,
-                                   int32_t variant, rg_stream_t stream) {
+                                   const float* weights, int64_t n_vox, int64_t n_pairs, int64_t line_len,
+                                   const float* packed, int32_t n_fields, int32_t stride, int64_t n_gates,
+                                   float fill_value, float* out, int32_t variant, rg_stream_t stream) {
   RG_REQUIRE(indptr && out, RG_EINVAL, "rg_csr_apply_f32: null indptr/out");
   RG_REQUIRE(n_vox >= 0 && n_pairs >= 0, RG_EINVAL, "rg_csr_apply_f32: negative size");
   RG_REQUIRE(n_fields >= 1 && n_fields <= RG_MAX_FIELDS, RG_EUNSUPPORTED, "rg_csr_apply_f32: n_fields=%d not in 1..%d",
@@ -331,18 +333,21 @@ extern "C" int rg_csr_apply_f32_ex(const void* indptr, int32_t indptr_is_i64, co
   RG_REQUIRE(n_vox <= 0x3FFFFFFFFFL, RG_EUNSUPPORTED, "rg_csr_apply_f32: n_vox too large for one launch");
   RG_REQUIRE(rg::aligned16(packed), RG_EALIGN, "rg_csr_apply_f32: packed must be 16-byte aligned");
   if (n_vox == 0) return RG_OK;
+  if (line_len <= 0) line_len = n_vox;   // no grid lines known: one line, plain 64-row segments
+  RG_REQUIRE(n_vox % line_len == 0, RG_EINVAL, "rg_csr_apply_f32: n_vox=%ld is not a multiple of line_len=%ld",
+             (long)n_vox, (long)line_len);
   hipStream_t s = (hipStream_t)stream;
   if (indptr_is_i64)
-    return dispatch<int64_t>(n_fields, variant, indptr, gate_idx, weights, n_vox, n_pairs, packed, n_gates, fill_value,
+    return dispatch<int64_t>(n_fields, variant, indptr, gate_idx, weights, n_vox, line_len, packed, n_gates, fill_value,
                              out, s);
-  return dispatch<int32_t>(n_fields, variant, indptr, gate_idx, weights, n_vox, n_pairs, packed, n_gates, fill_value, out,
+  return dispatch<int32_t>(n_fields, variant, indptr, gate_idx, weights, n_vox, line_len, packed, n_gates, fill_value, out,
                            s);
 }
 
 extern "C" int rg_csr_apply_f32(const void* indptr, int32_t indptr_is_i64, const int32_t* gate_idx,
-                                const float* weights, int64_t n_vox, int64_t n_pairs, const float* packed,
-                                int32_t n_fields, int32_t stride, int64_t n_gates, float fill_value, float* out,
-                                rg_stream_t stream) {
-  return rg_csr_apply_f32_ex(indptr, indptr_is_i64, gate_idx, weights, n_vox, n_pairs, packed, n_fields, stride, n_gates,
-                             fill_value, out, 0, stream);
+                                const float* weights, int64_t n_vox, int64_t n_pairs, int64_t line_len,
+                                const float* packed, int32_t n_fields, int32_t stride, int64_t n_gates, float fill_value,
+                                float* out, rg_stream_t stream) {
+  return rg_csr_apply_f32_ex(indptr, indptr_is_i64, gate_idx, weights, n_vox, n_pairs, line_len, packed, n_fields, stride,
+                             n_gates, fill_value, out, 0, stream);
 }

@@ -1,30 +1,39 @@
 // K1c  csr_apply over a COMPACT device copy of the CSR (same results as rg_csr_apply_f32, bit for bit).
 //
 // The reference's CSR (radar_grid/geometry.py:46-52) stores a 32-bit gate index per pair, and K1 pays for it twice:
-// 4 of the 8 streamed bytes per pair, and one global gather per pair, which the texture-address path serves at about
-// 22 cycles per 64-lane instruction wherever the gates lie.  Neighbouring voxels share almost all
-// their gates, so this copy groups RG_COMPACT_ROWS = 256 consecutive rows into a chunk, lists the chunk's DISTINCT
-// gates once (`dict`, ascending gate index) and stores a 16-bit position in that list per pair:
+// 4 of the 8 streamed bytes per pair, and one global gather per pair (F values wide), which the texture-address path
+// serves at about 22 cycles per 64-lane instruction wherever the gates lie.  Neighbouring voxels share
+// almost all their gates, so this copy groups the rows of a small 2-D PATCH of the grid into a chunk, lists the chunk's
+// DISTINCT gates once (`dict`) and stores a 16-bit position in that list per pair:
 //
-//   bytes per pair 8 -> 6 (+ 4 bytes per distinct gate per chunk, ~0.7 bytes per pair on the bench geometry);
-//   one workgroup = one chunk: it gathers the chunk's ~1000 field values into an LDS window once (coalesced reads of
-//   `dict`, one gather per DISTINCT gate) and every pair then reads its value from LDS.  The window holds
-//   `window_cap` values (chosen per geometry to cover all but a handful of chunks -- those next to the radar, where
-//   every ray converges); a chunk with more distinct gates gathers per pair through its dictionary instead.
+//   chunk (plane z, line group yg, segment sx) = the segments sx of the H consecutive grid lines y = yg*H .. yg*H+H-1
+//   of plane z; a segment = up to 64 consecutive rows of one line, exactly the unit one wavefront of rg_csr_apply_f32
+//   owns.  A chunk therefore covers H x 64 voxels (H = RG_COMPACT_LINES = 4: 256 rows), a patch instead of a 256 x 1
+//   strip: 2-3x fewer distinct gates per chunk, hence a smaller LDS window, more resident workgroups and fewer
+//   dictionary bytes (measured per configuration in DESIGN.md);
+//   bytes per pair 8 -> 6 (+ 4 bytes per distinct gate per chunk, 0.1-0.4 bytes per pair);
+//   one workgroup = one chunk = H wavefronts: it gathers the chunk's few hundred field entries (F values each, the
+//   rg_pack_fields_f32 layout) into an LDS window once -- coalesced reads of `dict`, one global gather per DISTINCT
+//   gate -- and every pair then reads its values from LDS.  The window holds `window_cap` entries (chosen per geometry
+//   to cover all but a handful of chunks -- those next to the radar, where every ray converges); a chunk with more
+//   distinct gates gathers per pair through its dictionary instead.
 //
-// Pair order, weights and the float32 arithmetic are those of rg_csr_apply_f32 (same tiles, same products, same
-// dynamic row phase), so the two kernels agree exactly; the compact copy is derived from the standard CSR on the
-// device (gridding.CompactCsr) and the standard arrays stay the interchange format.
+// Pair order, weights, tiles and the float32 arithmetic are those of rg_csr_apply_f32 (same segments, same tiles, same
+// products, same dynamic row phase), so the two kernels agree exactly for every field count; the compact copy is
+// derived from the standard CSR on the device (grid_geometry.CompactCSR) and the standard arrays stay the
+// interchange format.
 //
 // Roofline: HBM.  Bytes per launch = 6*P + 4*D + sizeof(indptr)*(V+1) + 8*(C+1) + F*(5*G + 4*V)  with D = total
 // dictionary entries, C = chunks.
 #include <type_traits>
 
 #include "rg_common.hpp"
+#include "rg_row_phase.hpp"
 
 namespace {
 
-using f32x2 = float __attribute__((ext_vector_type(2)));
+using rg::f32x2;
+using rg::f32x4;
 using rsrc_t = __amdgpu_buffer_rsrc_t;
 constexpr int kRsrcRaw32 = 0x00020000;   // gfx9 buffer resource word 3: DATA_FORMAT = 32, untyped access
 
@@ -33,41 +42,97 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* base, long bytes) {   //
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)nb, kRsrcRaw32);
 }
 
-constexpr int kWaves = RG_COMPACT_ROWS / 64;   // 4 wavefronts of 64 rows per chunk
+constexpr int kH = RG_COMPACT_LINES;   // grid lines (= wavefronts) per chunk
 
-template <typename IndT, int TILE>
-__global__ __launch_bounds__(64 * kWaves) void csr_compact_kernel(
+// Where a chunk's wavefronts find their rows: the grid as planes x lines x rows (nz x ny x nx for a radar grid).
+// Chunk arithmetic is 32-bit on purpose: every wavefront decodes its chunk number with two divisions, and a 64-bit
+// division costs this ISA a few hundred instructions (measured: 7 % of the single-field kernel).
+struct ChunkGrid {
+  long line_len;            // rows per line (nx)
+  long lines_per_plane;     // lines per plane (ny)
+  long n_planes;            // planes (nz)
+  unsigned nsx;             // segments per line = ceil(line_len / 64)
+  unsigned nyg;             // line groups per plane = ceil(lines_per_plane / H)
+  unsigned rot_step;        // columns the block -> chunk map rotates per line group (speed only)
+  unsigned seg_base;        // a line's nsx segments are balanced: the first seg_extra hold seg_base + 1 rows, the
+  unsigned seg_extra;       // others seg_base (<= 64 either way) -- rg_csr_apply_f32 cuts its lines the same way
+};
+
+__host__ __device__ inline long chunk_count(const ChunkGrid& g) { return g.n_planes * (long)g.nyg * (long)g.nsx; }
+
+struct Segment {
+  long r0;      // first row
+  int nrows;    // 0 for a wavefront past the last line of the plane
+};
+
+__device__ __forceinline__ Segment chunk_segment(const ChunkGrid& g, unsigned chunk, int w) {   // chunk < 2^31
+  const unsigned grp = chunk / g.nsx;         // line group, counted through all planes
+  const unsigned sx = chunk - grp * g.nsx;
+  const unsigned plane = grp / g.nyg;
+  const unsigned yg = grp - plane * g.nyg;
+  const long y = (long)yg * kH + w;
+  Segment s;
+  if (y >= g.lines_per_plane) {
+    s.r0 = 0;
+    s.nrows = 0;
+    return s;
+  }
+  const unsigned x0 = sx * g.seg_base + (sx < g.seg_extra ? sx : g.seg_extra);
+  s.r0 = ((long)plane * g.lines_per_plane + y) * g.line_len + (long)x0;
+  s.nrows = (int)(g.seg_base + (sx < g.seg_extra ? 1u : 0u));
+  return s;
+}
+
+template <typename IndT, int NF, int STRIDE, int TILE>
+__global__ __launch_bounds__(64 * kH) void csr_compact_kernel(
     const IndT* __restrict__ indptr, const uint16_t* __restrict__ lidx, const float* __restrict__ wts,
-    const int64_t* __restrict__ dict_ptr, const int32_t* __restrict__ dict, long n_vox,
-    const float* __restrict__ packed, unsigned last_gate, float fill, int window_cap, float* __restrict__ out) {
+    const int64_t* __restrict__ dict_ptr, const int32_t* __restrict__ dict, ChunkGrid cg,
+    const float* __restrict__ packed, unsigned last_gate, float fill, int window_cap, long n_vox,
+    float* __restrict__ out) {
   static_assert(TILE % 64 == 0, "a wave handles 64 pairs per step");
   constexpr int IT = TILE / 64;
-  extern __shared__ float window[];                  // field values of the chunk's distinct gates (window_cap entries)
-  __shared__ f32x2 tile_all[kWaves][TILE];
-  __shared__ f32x2 rowacc_all[kWaves][64];
+  extern __shared__ __attribute__((aligned(16))) float window[];   // window_cap entries of STRIDE floats
+  __shared__ __attribute__((aligned(16))) float tile_all[kH][TILE * rg::tile_floats(NF, STRIDE)];
+  __shared__ f32x2 rowacc_all[kH][64 * STRIDE];
+  static_assert((sizeof(tile_all) + sizeof(rowacc_all)) % 16 == 0,
+                "the dynamic window starts where the static arrays end and is accessed 16 bytes wide");
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  f32x2* tile = tile_all[wv];
+  float* tile = tile_all[wv];
   f32x2* rowacc = rowacc_all[wv];
 
-  const long chunk = blockIdx.x;
+  // Workgroups are dealt to the 8 XCDs round-robin by blockIdx.  With nsx segments per line a multiple of 8, chunk
+  // column sx would always land on XCD sx % 8; rotating the columns by one per line group makes every XCD see every
+  // column (speed only: the chunk a workgroup takes is still a bijection of blockIdx).
+  const unsigned grp = blockIdx.x / cg.nsx;
+  const unsigned col = blockIdx.x - grp * cg.nsx;
+  const unsigned rot = (col + (grp * cg.rot_step) % cg.nsx);
+  const unsigned chunk = grp * cg.nsx + (rot >= cg.nsx ? rot - cg.nsx : rot);
   const long d0 = dict_ptr[chunk];
-  const int nd = (int)(dict_ptr[chunk + 1] - d0);    // <= 65536: positions are 16 bits
-  const bool windowed = nd <= window_cap;            // workgroup-uniform; the rare wider chunk gathers per pair
+  // A chunk's dictionary holds at most 65536 gates (positions are 16 bits).  The one exception is a SPLIT chunk -- more
+  // distinct gates than that, as around the radar itself on a dense scan --, which stores one dictionary per wavefront
+  // behind a header of kH offsets; its entry count (header included) exceeds 65536, which is how it is recognised.
+  const int nd_all = (int)(dict_ptr[chunk + 1] - d0);
+  const bool split = nd_all > 65536;
+  const bool windowed = nd_all <= window_cap;        // workgroup-uniform; the rare wider chunk gathers per pair
+  const int w_lo = split ? dict[d0 + wv] : 0;
+  const int w_hi = split ? (wv + 1 < kH ? dict[d0 + wv + 1] : nd_all) : nd_all;
+  const int nd = w_hi - w_lo;                        // entries of the dictionary this wavefront's positions refer to
   const int nd_last = nd > 0 ? nd - 1 : 0;
-  const int32_t* __restrict__ cdict = dict + d0;
+  const int32_t* __restrict__ cdict = dict + d0 + w_lo;
 
-  const long r0 = chunk * RG_COMPACT_ROWS + (long)wv * 64;
-  const bool alive = r0 < n_vox;                     // wave-uniform; a dead wave still helps to fill the window
-  const long row = r0 + lane;
-  const long seg_b = alive ? (long)indptr[r0] : 0;
-  const long seg_e = alive ? (long)indptr[r0 + 64 < n_vox ? r0 + 64 : n_vox] : 0;
+  const Segment sg = chunk_segment(cg, chunk, wv);
+  const int nrows = sg.nrows;                        // wave-uniform; a wave without rows still helps to fill the window
+  const long r0 = sg.r0;
+  const long seg_b = nrows ? (long)indptr[r0] : 0;
+  const long seg_e = nrows ? (long)indptr[r0 + nrows] : 0;
   const int span = (int)(seg_e - seg_b);
-  const int rs_o = alive ? (int)((long)indptr[row < n_vox ? row : n_vox] - seg_b) : 0;
-  const int re_o = alive ? (int)((long)indptr[row + 1 < n_vox ? row + 1 : n_vox] - seg_b) : 0;
-  rowacc[lane] = (f32x2)(0.0f);
+  const int rs_o = nrows ? (int)((long)indptr[r0 + (lane < nrows ? lane : nrows)] - seg_b) : 0;
+  const int re_o = nrows ? (int)((long)indptr[r0 + (lane + 1 < nrows ? lane + 1 : nrows)] - seg_b) : 0;
+#pragma unroll
+  for (int f = 0; f < STRIDE; ++f) rowacc[lane * STRIDE + f] = (f32x2)(0.0f);
 
-  // Two register stages, loop unrolled by two, every load unconditional and range-checked against the chunk's last
+  // Two register stages, loop unrolled by two, every load unconditional and range-checked against the segment's last
   // pair -- the same exact-wait-count pipeline as rg_csr_apply_f32, without a gather stage.
   struct Stage {
     int ci[IT];
@@ -77,13 +142,13 @@ __global__ __launch_bounds__(64 * kWaves) void csr_compact_kernel(
   const uint16_t* __restrict__ li = lidx + seg_b;
   const float* __restrict__ wi = wts + seg_b;
   const int lane2 = lane * 2, lane4 = lane * 4;
-  auto stream = [&](Stage& sg, int t) {   // t wave-uniform: the resources live in SGPRs
+  auto stream = [&](Stage& sgs, int t) {   // t wave-uniform: the resources live in SGPRs
     const rsrc_t ri = make_rsrc(li + t, ((long)span - t) * 2);
     const rsrc_t rw = make_rsrc(wi + t, ((long)span - t) * 4);
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
-      sg.ci[it] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(ri, lane2 + it * 128, 0, 0);
-      sg.cw[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, lane4 + it * 256, 0, 0));
+      sgs.ci[it] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(ri, lane2 + it * 128, 0, 0);
+      sgs.cw[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, lane4 + it * 256, 0, 0));
     }
   };
   // the first two tiles are requested BEFORE the window is filled: the two latencies overlap
@@ -92,70 +157,63 @@ __global__ __launch_bounds__(64 * kWaves) void csr_compact_kernel(
 
   // ---- the chunk's field window: one gather per DISTINCT gate --------------------------------------------
   if (windowed) {
-    for (int i = threadIdx.x; i < nd; i += 64 * kWaves) {
-      const unsigned g = (unsigned)dict[d0 + i];
-      window[i] = packed[g < last_gate ? g : last_gate];   // clamp: never fault
+    for (int i = threadIdx.x; i < nd_all; i += 64 * kH) {
+      const unsigned g0 = (unsigned)cdict[i];
+      const unsigned g = g0 < last_gate ? g0 : last_gate;   // clamp: never fault
+      float v[STRIDE];
+      rg::load_packed<STRIDE>(packed, g, v);
+      if constexpr (STRIDE == 1) {
+        window[i] = v[0];
+      } else if constexpr (STRIDE == 2) {
+        reinterpret_cast<f32x2*>(window)[i] = (f32x2){v[0], v[1]};
+      } else {
+#pragma unroll
+        for (int q = 0; q < STRIDE; q += 4)
+          reinterpret_cast<f32x4*>(window)[(size_t)i * (STRIDE / 4) + q / 4] = (f32x4){v[q], v[q + 1], v[q + 2], v[q + 3]};
+      }
     }
   }
   __syncthreads();
 
-  if (span > 0) {
+  // The tile loop exists twice -- values from the LDS window, or (over-wide chunk) position -> gate -> value from memory
+  // -- selected once per workgroup: a uniform branch INSIDE the unrolled loads made this compiler drop the register
+  // copies of the last windowed read of a tile (3-field kernel, seen in the ISA), and the loop is leaner without it.
+  auto run = [&](auto wtag) {
+    constexpr bool kWindowed = decltype(wtag)::value;
     auto step = [&](int t, Stage& cur) {
-      // ---- products of tile t -> LDS (values come from the window) -----------------------------------
-      float val[IT];
-      if (windowed) {
-#pragma unroll
-        for (int it = 0; it < IT; ++it) val[it] = window[cur.ci[it] < nd_last ? cur.ci[it] : nd_last];
-      } else {   // chunk with more distinct gates than the window holds: position -> gate -> value, from memory
-#pragma unroll
-        for (int it = 0; it < IT; ++it) {
-          const unsigned g = (unsigned)cdict[cur.ci[it] < nd_last ? cur.ci[it] : nd_last];
-          val[it] = packed[g < last_gate ? g : last_gate];
-        }
-      }
+      // ---- values of tile t ---------------------------------------------------------------------------------
+      float val[IT][STRIDE];
 #pragma unroll
       for (int it = 0; it < IT; ++it) {
-        const bool ok = rg::f32_bits(val[it]) != RG_EXCLUDED_BITS;
-        f32x2 e;
-        e.x = ok ? cur.cw[it] * val[it] : 0.0f;
-        e.y = ok ? cur.cw[it] : 0.0f;
-        tile[it * 64 + lane] = e;
+        const int pos = cur.ci[it] < nd_last ? cur.ci[it] : nd_last;
+        if constexpr (kWindowed) {
+          if constexpr (STRIDE == 1) {
+            val[it][0] = window[pos];
+          } else if constexpr (STRIDE == 2) {
+            const f32x2 q = reinterpret_cast<const f32x2*>(window)[pos];
+            val[it][0] = q.x; val[it][1] = q.y;
+          } else {
+#pragma unroll
+            for (int s = 0; s < STRIDE; s += 4) {
+              const f32x4 q = reinterpret_cast<const f32x4*>(window)[(size_t)pos * (STRIDE / 4) + s / 4];
+              val[it][s] = q.x; val[it][s + 1] = q.y; val[it][s + 2] = q.z; val[it][s + 3] = q.w;
+            }
+          }
+        } else {
+          const unsigned g0 = (unsigned)cdict[pos];
+          rg::load_packed<STRIDE>(packed, g0 < last_gate ? g0 : last_gate, val[it]);
+        }
       }
+      // ---- products of tile t -> LDS (layout and arithmetic: rg_row_phase.hpp) ----------------------------------
+#pragma unroll
+      for (int it = 0; it < IT; ++it) rg::store_products<NF, STRIDE>(tile, TILE, it * 64 + lane, cur.cw[it], val[it]);
       stream(cur, t + 2 * TILE);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-      // ---- dynamic row phase (identical to rg_csr_apply_f32 with one field slot) ---------------------------
-      const unsigned long long act = __ballot(re_o > rs_o && re_o > t && rs_o < t + TILE);
-      if (act != 0) {  // wave-uniform
-        const int ra = __builtin_ctzll(act), rb = 63 - __builtin_clzll(act);
-        const int nact = rb - ra + 1;
-        const int lg = 31 - __builtin_clz(64 / nact);    // lanes per row = 2^lg <= 64 / rows
-        const int rpr = 64 >> lg;                        // rows per round
-        const int sub = lane & ((1 << lg) - 1), nsub = 1 << lg;
-        for (int rbase = ra; rbase <= rb; rbase += rpr) {
-          const int myrow = rbase + (lane >> lg);
-          const bool live = myrow <= rb;
-          const int qs = __shfl(rs_o, myrow & 63, 64);
-          const int qe = __shfl(re_o, myrow & 63, 64);
-          const int a = (qs > t ? qs : t) - t;
-          const int b = live ? (qe < t + TILE ? qe : t + TILE) - t : a;
-          f32x2 part0 = (f32x2)(0.0f), part1 = (f32x2)(0.0f);
-          int j = a + sub;
-          for (; j + nsub < b; j += 2 * nsub) {  // two elements per trip, two independent partial sums
-            part0 += tile[j];
-            part1 += tile[j + nsub];
-          }
-          if (j < b) part0 += tile[j];
-          f32x2 sum = part0 + part1;
-          for (int m = 1; m < (1 << lg); m <<= 1) {
-            sum.x += __shfl_xor(sum.x, m, 64);
-            sum.y += __shfl_xor(sum.y, m, 64);
-          }
-          if (live && sub == 0) rowacc[myrow] += sum;
-        }
-      }
+      // ---- dynamic row phase (shared with rg_csr_apply_f32: same lane split, same float32 adds) ----------------
+      rg::row_phase<NF, STRIDE, TILE>(tile, rowacc, t, rs_o, re_o, lane);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -169,55 +227,141 @@ __global__ __launch_bounds__(64 * kWaves) void csr_compact_kernel(
         if (t >= span) break;
       }
     }
+  };
+  if (span > 0) {
+    if (windowed) run(std::true_type{}); else run(std::false_type{});
   }
 
-  if (row < n_vox) {
-    const f32x2 s = rowacc[lane];
-    out[row] = s.y > 0.0f ? (float)((double)s.x / (double)s.y) : fill;
+  if (lane < nrows) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const f32x2 s = rowacc[lane * STRIDE + f];
+      out[(size_t)f * n_vox + r0 + lane] = s.y > 0.0f ? (float)((double)s.x / (double)s.y) : fill;
+    }
   }
 }
 
+constexpr int stride_for(int nf) { return nf == 1 ? 1 : nf == 2 ? 2 : nf <= 4 ? 4 : 8; }
+
+template <typename IndT, int NF, int TILE>
+constexpr size_t static_lds() {
+  return (size_t)kH * (TILE * rg::tile_floats(NF, stride_for(NF)) * 4 + 64 * stride_for(NF) * 8);
+}
+
+template <typename IndT, int NF, int TILE>
+int launch_nf(int window_cap, const void* indptr, const uint16_t* lidx, const float* wts, const int64_t* dict_ptr,
+              const int32_t* dict, const ChunkGrid& cg, long n_vox, const float* packed, long n_gates, float fill,
+              float* out, hipStream_t s) {
+  constexpr int STRIDE = stride_for(NF);
+  // static + dynamic LDS of one workgroup stay within the 64 KiB a launch gets without opting in to more; a window
+  // smaller than the geometry asked for only sends more chunks down the per-pair path (same results)
+  const long room = (65536 - (long)static_lds<IndT, NF, TILE>() - 256) / (4 * STRIDE);
+  if (window_cap > room) window_cap = (int)(room < 0 ? 0 : room);
+  hipLaunchKernelGGL((csr_compact_kernel<IndT, NF, STRIDE, TILE>), dim3((unsigned)chunk_count(cg)), dim3(64 * kH),
+                     (size_t)window_cap * STRIDE * sizeof(float), s, static_cast<const IndT*>(indptr), lidx, wts, dict_ptr,
+                     dict, cg, packed, (unsigned)(n_gates - 1), fill, window_cap, n_vox, out);
+  return rg::check_launch("rg_csr_compact_apply_f32");
+}
+
+// Tiles: the defaults MUST be the tiles rg_csr_apply_f32 uses for the same field count (same partial sums).
 template <typename IndT>
-int launch(int tile, int window_cap, const void* indptr, const uint16_t* lidx, const float* wts, const int64_t* dict_ptr,
-           const int32_t* dict, long n_vox, const float* packed, long n_gates, float fill, float* out, hipStream_t s) {
-  const long chunks = (n_vox + RG_COMPACT_ROWS - 1) / RG_COMPACT_ROWS;
-#define RG_K1C(TILE_)                                                                                                 \
-  hipLaunchKernelGGL((csr_compact_kernel<IndT, TILE_>), dim3((unsigned)chunks), dim3(64 * kWaves),                    \
-                     (size_t)window_cap * sizeof(float), s, static_cast<const IndT*>(indptr), lidx, wts, dict_ptr, dict, \
-                     n_vox, packed, (unsigned)(n_gates - 1), fill, window_cap, out)
-  switch (tile) {   // the default must be the tile of rg_csr_apply_f32's single-field kernel: same partial sums
-    case 256: RG_K1C(256); break;
-    case 512: RG_K1C(512); break;
-    default: RG_K1C(384); break;
+int launch(int nf, int tile, int window_cap, const void* indptr, const uint16_t* lidx, const float* wts,
+           const int64_t* dict_ptr, const int32_t* dict, const ChunkGrid& cg, long n_vox, const float* packed, long n_gates,
+           float fill, float* out, hipStream_t s) {
+#define RG_K1C(NF_, TILE_) \
+  launch_nf<IndT, NF_, TILE_>(window_cap, indptr, lidx, wts, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s)
+  switch (nf) {
+    case 1:
+      switch (tile) {
+        case 256: return RG_K1C(1, 256);
+        case 512: return RG_K1C(1, 512);
+        default: return RG_K1C(1, 384);
+      }
+    case 2:
+      switch (tile) {
+        case 128: return RG_K1C(2, 128);
+        case 512: return RG_K1C(2, 512);
+        default: return RG_K1C(2, 256);
+      }
+    case 3:
+      switch (tile) {
+        case 128: return RG_K1C(3, 128);
+        case 384: return RG_K1C(3, 384);
+        default: return RG_K1C(3, 256);
+      }
+    case 4:
+      switch (tile) {
+        case 128: return RG_K1C(4, 128);
+        default: return RG_K1C(4, 256);
+      }
+    case 5: return RG_K1C(5, 128);
+    case 6: return RG_K1C(6, 128);
+    case 7: return RG_K1C(7, 128);
+    default: return RG_K1C(8, 128);
   }
 #undef RG_K1C
-  return rg::check_launch("rg_csr_compact_apply_f32");
+}
+
+bool make_chunk_grid(int64_t n_rows, int64_t line_len, int64_t lines_per_plane, ChunkGrid* cg) {
+  if (line_len <= 0) line_len = n_rows > 0 ? n_rows : 1;
+  if (n_rows % line_len != 0) return false;
+  const long n_lines = n_rows / line_len;
+  if (lines_per_plane <= 0) lines_per_plane = n_lines > 0 ? n_lines : 1;
+  if (n_lines % lines_per_plane != 0) return false;
+  cg->line_len = line_len;
+  cg->lines_per_plane = lines_per_plane;
+  cg->n_planes = n_lines / lines_per_plane;
+  const long nsx = (line_len + 63) / 64, nyg = (lines_per_plane + kH - 1) / kH;
+  if (nsx > 0x7FFFFFFFL || nyg > 0x7FFFFFFFL) return false;
+  cg->nsx = (unsigned)nsx;
+  cg->nyg = (unsigned)nyg;
+  cg->seg_base = (unsigned)(line_len / nsx);
+  cg->seg_extra = (unsigned)(line_len % nsx);
+  cg->rot_step = 1;   // measured on the bench grid: 0 -> 14.2 ms, 1 -> 9.8, 2 -> 9.7, 3 -> 9.8, 5 -> 9.6, 8 -> 10.5, 13 -> 9.8
+  return true;
 }
 
 }  // namespace
 
+extern "C" int64_t rg_csr_compact_chunks(int64_t n_rows, int64_t line_len, int64_t lines_per_plane) {
+  ChunkGrid cg;
+  if (n_rows < 0 || !make_chunk_grid(n_rows, line_len, lines_per_plane, &cg)) return RG_EINVAL;
+  return n_rows == 0 ? 0 : chunk_count(cg);
+}
+
 extern "C" int rg_csr_compact_apply_f32(const void* indptr, int32_t indptr_is_i64, const uint16_t* local_idx,
                                         const float* weights, const int64_t* dict_ptr, const int32_t* dict,
-                                        int64_t n_vox, int64_t n_pairs, const float* packed, int64_t n_gates,
+                                        int64_t n_vox, int64_t n_pairs, int64_t line_len, int64_t lines_per_plane,
+                                        const float* packed, int32_t n_fields, int32_t stride, int64_t n_gates,
                                         float fill_value, float* out, int32_t window_cap, int32_t tile,
                                         rg_stream_t stream) {
   RG_REQUIRE(indptr && out && dict_ptr, RG_EINVAL, "rg_csr_compact_apply_f32: null indptr/dict_ptr/out");
   RG_REQUIRE(n_vox >= 0 && n_pairs >= 0, RG_EINVAL, "rg_csr_compact_apply_f32: negative size");
+  RG_REQUIRE(n_fields >= 1 && n_fields <= RG_MAX_FIELDS, RG_EUNSUPPORTED,
+             "rg_csr_compact_apply_f32: n_fields=%d not in 1..%d", n_fields, RG_MAX_FIELDS);
+  RG_REQUIRE(stride == stride_for(n_fields), RG_EINVAL, "rg_csr_compact_apply_f32: stride=%d, expected %d for %d fields",
+             stride, stride_for(n_fields), n_fields);
   RG_REQUIRE(n_pairs == 0 || (local_idx && weights && dict && packed && n_gates > 0), RG_EINVAL,
              "rg_csr_compact_apply_f32: pairs present but local_idx/weights/dict/packed/n_gates missing");
   RG_REQUIRE(n_gates <= 0x7FFFFFFFL, RG_EUNSUPPORTED, "rg_csr_compact_apply_f32: n_gates exceeds int32 gate indices");
   RG_REQUIRE(n_vox <= 0x3FFFFFFFFFL, RG_EUNSUPPORTED, "rg_csr_compact_apply_f32: n_vox too large for one launch");
-  RG_REQUIRE(tile == 0 || tile == 256 || tile == 384 || tile == 512, RG_EINVAL,
-             "rg_csr_compact_apply_f32: tile must be 0 (default), 256, 384 or 512");
+  RG_REQUIRE(tile == 0 || tile == 128 || tile == 256 || tile == 384 || tile == 512, RG_EINVAL,
+             "rg_csr_compact_apply_f32: tile must be 0 (default), 128, 256, 384 or 512");
   RG_REQUIRE(window_cap >= 0 && window_cap <= RG_COMPACT_MAX_WINDOW, RG_EINVAL,
              "rg_csr_compact_apply_f32: window_cap %d outside 0..%d", window_cap, RG_COMPACT_MAX_WINDOW);
+  RG_REQUIRE(rg::aligned16(packed), RG_EALIGN, "rg_csr_compact_apply_f32: packed must be 16-byte aligned");
   if (n_vox == 0) return RG_OK;
+  ChunkGrid cg;
+  RG_REQUIRE(make_chunk_grid(n_vox, line_len, lines_per_plane, &cg), RG_EINVAL,
+             "rg_csr_compact_apply_f32: n_vox=%ld is not planes x lines_per_plane=%ld x line_len=%ld", (long)n_vox,
+             (long)lines_per_plane, (long)line_len);
+  RG_REQUIRE(chunk_count(cg) <= 0x7FFFFFFFL, RG_EUNSUPPORTED, "rg_csr_compact_apply_f32: too many chunks for one launch");
   hipStream_t s = (hipStream_t)stream;
   if (indptr_is_i64)
-    return launch<int64_t>(tile, window_cap, indptr, local_idx, weights, dict_ptr, dict, n_vox, packed, n_gates,
-                           fill_value, out, s);
-  return launch<int32_t>(tile, window_cap, indptr, local_idx, weights, dict_ptr, dict, n_vox, packed, n_gates, fill_value,
-                         out, s);
+    return launch<int64_t>(n_fields, tile, window_cap, indptr, local_idx, weights, dict_ptr, dict, cg, n_vox, packed,
+                           n_gates, fill_value, out, s);
+  return launch<int32_t>(n_fields, tile, window_cap, indptr, local_idx, weights, dict_ptr, dict, cg, n_vox, packed, n_gates,
+                         fill_value, out, s);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -229,6 +373,8 @@ extern "C" int rg_csr_compact_apply_f32(const void* indptr, int32_t indptr_is_i6
 //   fill pass : same rounds; the lane that claims a slot gives the gate the next position and writes the dictionary
 //               entry, a second sweep over the round's pairs looks every gate up and stores its 16-bit position.
 // Positions depend on the insertion order (not reproducible run to run); the gridding result does not.
+// `gate_idx` / `local_idx` are addressed by ABSOLUTE pair number (indptr values), so a caller that holds only a slab of
+// the index array passes pointers shifted by the slab's first pair.
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
 
@@ -236,43 +382,63 @@ constexpr int kSlots = 8192;          // hash slots per workgroup (32 KiB)
 constexpr int kMaxLoad = 6144;        // distinct gates one round may insert
 constexpr int kBuildThreads = 256;
 constexpr int kMaxRounds = 32;
+constexpr int kSplitFlag = 0x80;               // chunk_rounds bit: one dictionary per wavefront (see the apply kernel)
+constexpr int kNotCompactable = 0x40000000;    // chunk_counts value: a single segment references > 65536 gates
 
 __device__ __forceinline__ unsigned slot_hash(unsigned g) { return (g * 2654435761u) >> 19; }      // 13 bits
 __device__ __forceinline__ unsigned round_hash(unsigned g) { return (g * 0x85EBCA6Bu) >> 27; }     // 5 bits
 
-// Inserts the gates of residue class `r` (of `rounds`) among pairs [p0, p1).  Returns false when the table overloads.
+struct ChunkPairs {   // the (up to) H contiguous pair ranges of one chunk
+  long p0[kH], p1[kH];
+};
+
+template <typename IndT>
+__device__ __forceinline__ ChunkPairs chunk_pairs(const IndT* __restrict__ indptr, const ChunkGrid& cg, unsigned chunk) {
+  ChunkPairs cp;
+#pragma unroll
+  for (int w = 0; w < kH; ++w) {
+    const Segment s = chunk_segment(cg, chunk, w);
+    cp.p0[w] = s.nrows ? (long)indptr[s.r0] : 0;
+    cp.p1[w] = s.nrows ? (long)indptr[s.r0 + s.nrows] : 0;
+  }
+  return cp;
+}
+
+// Inserts the gates of residue class `r` (of `rounds`) among the chunk's pairs.  Returns false when the table overloads.
 // With `ids`, the lane that claims a slot also gives the gate its position (base + order of arrival) and writes the
 // dictionary entry: positions then follow the order in which the chunk's pairs first mention a gate, so the 64
 // consecutive pairs of one gather mostly hold neighbouring positions (fewer LDS bank conflicts than any fixed order).
-template <typename IndT>
-__device__ bool insert_round(const int32_t* __restrict__ gidx, long p0, long p1, int rounds, int r, int* table,
+__device__ bool insert_round(const int32_t* __restrict__ gidx, const ChunkPairs& cp, int rounds, int r, int* table,
                              int* s_count, int* s_overflow, unsigned short* ids = nullptr, int base = 0,
-                             int32_t* __restrict__ dict_out = nullptr) {
+                             int32_t* __restrict__ dict_out = nullptr, int room = 0) {
   for (int i = threadIdx.x; i < kSlots; i += kBuildThreads) table[i] = -1;
   if (threadIdx.x == 0) { *s_count = 0; *s_overflow = 0; }
   __syncthreads();
-  for (long p = p0 + threadIdx.x; p < p1; p += kBuildThreads) {
-    const int g = gidx[p];
-    if (rounds > 1 && (int)(round_hash((unsigned)g) & (unsigned)(rounds - 1)) != r) continue;
-    unsigned h = slot_hash((unsigned)g);
-    while (true) {
-      const int seen = *(volatile int*)&table[h];   // other lanes insert concurrently
-      if (seen == g) break;
-      if (seen == -1) {
-        if (*(volatile int*)s_overflow) break;
-        const int old = atomicCAS(&table[h], -1, g);
-        if (old == -1) {
-          const int order = atomicAdd(s_count, 1);
-          if (order >= kMaxLoad) *(volatile int*)s_overflow = 1;
-          if (ids) {
-            ids[h] = (unsigned short)(base + order);
-            dict_out[base + order] = g;
+#pragma unroll
+  for (int w = 0; w < kH; ++w) {
+    for (long p = cp.p0[w] + threadIdx.x; p < cp.p1[w]; p += kBuildThreads) {
+      const int g = gidx[p];
+      if (rounds > 1 && (int)(round_hash((unsigned)g) & (unsigned)(rounds - 1)) != r) continue;
+      unsigned h = slot_hash((unsigned)g);
+      for (int probe = 0; probe < kSlots; ++probe) {   // bounded: a full table ends the walk (overflow is flagged first)
+        const int seen = *(volatile int*)&table[h];   // other lanes insert concurrently
+        if (seen == g) break;
+        if (seen == -1) {
+          if (*(volatile int*)s_overflow) break;
+          const int old = atomicCAS(&table[h], -1, g);
+          if (old == -1) {
+            const int order = atomicAdd(s_count, 1);
+            if (order >= kMaxLoad) *(volatile int*)s_overflow = 1;
+            if (ids && base + order < room) {   // never writes past the dictionary the count pass sized
+              ids[h] = (unsigned short)(base + order);
+              dict_out[base + order] = g;
+            }
+            break;
           }
-          break;
+          if (old == g) break;
         }
-        if (old == g) break;
+        h = (h + 1) & (kSlots - 1);
       }
-      h = (h + 1) & (kSlots - 1);
     }
   }
   __syncthreads();
@@ -281,97 +447,168 @@ __device__ bool insert_round(const int32_t* __restrict__ gidx, long p0, long p1,
 
 template <typename IndT>
 __global__ __launch_bounds__(kBuildThreads) void compact_count_kernel(const IndT* __restrict__ indptr,
-                                                                      const int32_t* __restrict__ gidx, long n_rows,
+                                                                      const int32_t* __restrict__ gidx, ChunkGrid cg,
                                                                       int32_t* __restrict__ chunk_counts,
                                                                       uint8_t* __restrict__ chunk_rounds) {
   __shared__ int table[kSlots];
   __shared__ int s_count, s_overflow;
-  const long chunk = blockIdx.x;
-  const long r0 = chunk * RG_COMPACT_ROWS;
-  const long r1 = r0 + RG_COMPACT_ROWS < n_rows ? r0 + RG_COMPACT_ROWS : n_rows;
-  const long p0 = (long)indptr[r0], p1 = (long)indptr[r1];
-  int rounds = 1, total = 0;
-  while (true) {
-    total = 0;
-    bool ok = true;
-    for (int r = 0; r < rounds && ok; ++r) {
-      ok = insert_round<IndT>(gidx, p0, p1, rounds, r, table, &s_count, &s_overflow);
-      total += s_count;
-      __syncthreads();
+  const unsigned chunk = blockIdx.x;
+  const ChunkPairs cp = chunk_pairs(indptr, cg, chunk);
+  // distinct gates among the given ranges, and the hashing rounds that took (-1: more than kMaxRounds can hold)
+  auto count = [&](const ChunkPairs& ranges, int& rounds) {
+    int total = 0;
+    while (true) {
+      total = 0;
+      bool ok = true;
+      for (int r = 0; r < rounds && ok; ++r) {
+        ok = insert_round(gidx, ranges, rounds, r, table, &s_count, &s_overflow);
+        total += s_count;
+        __syncthreads();
+      }
+      if (ok) return total;
+      rounds *= 2;
+      if (rounds > kMaxRounds) { rounds = kMaxRounds; return -1; }
     }
-    if (ok) break;
-    rounds *= 2;
-    if (rounds > kMaxRounds) { total = 65537; rounds = kMaxRounds; break; }   // not compactable
+  };
+  int rounds = 1;
+  int total = count(cp, rounds);
+  int flag = 0;
+  if (total < 0 || total > 65536) {
+    // too rich for 16-bit positions into ONE dictionary: one dictionary per wavefront (segment) instead, behind a
+    // header of kH offsets.  rounds = the most any of the wavefronts needs.
+    flag = kSplitFlag;
+    total = kH;
+    int worst = 1;
+    for (int w = 0; w < kH; ++w) {
+      ChunkPairs one;
+#pragma unroll
+      for (int k = 0; k < kH; ++k) { one.p0[k] = 0; one.p1[k] = 0; }
+      one.p0[0] = cp.p0[w];
+      one.p1[0] = cp.p1[w];
+      int rw = 1;
+      const int tw = count(one, rw);
+      if (tw < 0 || tw > 65536) { total = kNotCompactable; break; }
+      total += tw;
+      worst = rw > worst ? rw : worst;
+    }
+    rounds = worst;
   }
   if (threadIdx.x == 0) {
     chunk_counts[chunk] = total;
-    chunk_rounds[chunk] = (uint8_t)rounds;
+    chunk_rounds[chunk] = (uint8_t)(rounds | flag);
   }
 }
 
 template <typename IndT>
 __global__ __launch_bounds__(kBuildThreads) void compact_fill_kernel(const IndT* __restrict__ indptr,
-                                                                     const int32_t* __restrict__ gidx, long n_rows,
+                                                                     const int32_t* __restrict__ gidx, ChunkGrid cg,
                                                                      const int64_t* __restrict__ dict_ptr,
                                                                      const uint8_t* __restrict__ chunk_rounds,
                                                                      int32_t* __restrict__ dict,
-                                                                     uint16_t* __restrict__ local_idx) {
+                                                                     uint16_t* __restrict__ local_idx,
+                                                                     int32_t* __restrict__ error_flag) {
   __shared__ int table[kSlots];
   __shared__ unsigned short ids[kSlots];
   __shared__ int s_count, s_overflow;
-  const long chunk = blockIdx.x;
-  const long r0 = chunk * RG_COMPACT_ROWS;
-  const long r1 = r0 + RG_COMPACT_ROWS < n_rows ? r0 + RG_COMPACT_ROWS : n_rows;
-  const long p0 = (long)indptr[r0], p1 = (long)indptr[r1];
+  const unsigned chunk = blockIdx.x;
+  const ChunkPairs cp = chunk_pairs(indptr, cg, chunk);
   const long d0 = dict_ptr[chunk];
-  const int rounds = chunk_rounds[chunk];
-  int base = 0;
-  for (int r = 0; r < rounds; ++r) {
-    // cannot overload: the count pass sized the rounds
-    insert_round<IndT>(gidx, p0, p1, rounds, r, table, &s_count, &s_overflow, ids, base, dict + d0);
-    for (long p = p0 + threadIdx.x; p < p1; p += kBuildThreads) {
-      const int g = gidx[p];
-      if (rounds > 1 && (int)(round_hash((unsigned)g) & (unsigned)(rounds - 1)) != r) continue;
-      unsigned h = slot_hash((unsigned)g);
-      while (table[h] != g) h = (h + 1) & (kSlots - 1);
-      local_idx[p] = ids[h];
+  const int expect = (int)(dict_ptr[chunk + 1] - d0);
+  const int rounds = chunk_rounds[chunk] & (kSplitFlag - 1);
+  const bool split = (chunk_rounds[chunk] & kSplitFlag) != 0;
+  // positions of the given ranges' pairs into a dictionary written at dict_out; returns its size
+  auto fill = [&](const ChunkPairs& ranges, int32_t* __restrict__ dict_out, int room) {
+    int base = 0;
+    for (int r = 0; r < rounds; ++r) {
+      // cannot overload when the inputs are those of the count pass; if they are not (gate_idx changed in between, a
+      // wrong chunk_rounds) the walks below are bounded and the mismatch is reported through error_flag, never a hang
+      insert_round(gidx, ranges, rounds, r, table, &s_count, &s_overflow, ids, base, dict_out, room);
+      if (threadIdx.x == 0 && (s_overflow || base + s_count > room)) atomicOr(error_flag, 1);
+#pragma unroll
+      for (int w = 0; w < kH; ++w) {
+        for (long p = ranges.p0[w] + threadIdx.x; p < ranges.p1[w]; p += kBuildThreads) {
+          const int g = gidx[p];
+          if (rounds > 1 && (int)(round_hash((unsigned)g) & (unsigned)(rounds - 1)) != r) continue;
+          unsigned h = slot_hash((unsigned)g);
+          int probe = 0;
+          while (table[h] != g && probe < kSlots) { h = (h + 1) & (kSlots - 1); ++probe; }
+          if (probe == kSlots) {          // the gate was never inserted: count and fill saw different inputs
+            atomicOr(error_flag, 2);
+            local_idx[p] = 0;
+          } else {
+            local_idx[p] = ids[h];
+          }
+        }
+      }
+      base += s_count;
+      __syncthreads();
     }
-    base += s_count;
-    __syncthreads();
+    return base;
+  };
+  int base;
+  if (!split) {
+    base = fill(cp, dict + d0, expect < 65536 ? expect : 65536);
+  } else {
+    base = kH;                                       // header: offset of every wavefront's dictionary
+    for (int w = 0; w < kH; ++w) {
+      if (threadIdx.x == 0) dict[d0 + w] = base;
+      ChunkPairs one;
+#pragma unroll
+      for (int k = 0; k < kH; ++k) { one.p0[k] = 0; one.p1[k] = 0; }
+      one.p0[0] = cp.p0[w];
+      one.p1[0] = cp.p1[w];
+      const int left = expect - base;
+      base += fill(one, dict + d0 + base, left < 65536 ? (left > 0 ? left : 0) : 65536);
+    }
   }
+  if (threadIdx.x == 0 && base != expect) atomicOr(error_flag, 4);
 }
 
 }  // namespace
 
 extern "C" int rg_csr_compact_count(const void* indptr, int32_t indptr_is_i64, const int32_t* gate_idx, int64_t n_rows,
-                                    int32_t* chunk_counts, uint8_t* chunk_rounds, rg_stream_t stream) {
+                                    int64_t line_len, int64_t lines_per_plane, int32_t* chunk_counts,
+                                    uint8_t* chunk_rounds, rg_stream_t stream) {
   RG_REQUIRE(n_rows >= 0, RG_EINVAL, "rg_csr_compact_count: negative size");
   if (n_rows == 0) return RG_OK;
   RG_REQUIRE(indptr && chunk_counts && chunk_rounds, RG_EINVAL, "rg_csr_compact_count: null pointer");
-  const long chunks = (n_rows + RG_COMPACT_ROWS - 1) / RG_COMPACT_ROWS;
+  ChunkGrid cg;
+  RG_REQUIRE(make_chunk_grid(n_rows, line_len, lines_per_plane, &cg), RG_EINVAL,
+             "rg_csr_compact_count: n_rows=%ld is not planes x lines_per_plane=%ld x line_len=%ld", (long)n_rows,
+             (long)lines_per_plane, (long)line_len);
+  const long chunks = chunk_count(cg);
+  RG_REQUIRE(chunks <= 0x7FFFFFFFL, RG_EUNSUPPORTED, "rg_csr_compact_count: too many chunks for one launch");
   hipStream_t s = (hipStream_t)stream;
   if (indptr_is_i64)
     hipLaunchKernelGGL(compact_count_kernel<int64_t>, dim3((unsigned)chunks), dim3(kBuildThreads), 0, s,
-                       static_cast<const int64_t*>(indptr), gate_idx, (long)n_rows, chunk_counts, chunk_rounds);
+                       static_cast<const int64_t*>(indptr), gate_idx, cg, chunk_counts, chunk_rounds);
   else
     hipLaunchKernelGGL(compact_count_kernel<int32_t>, dim3((unsigned)chunks), dim3(kBuildThreads), 0, s,
-                       static_cast<const int32_t*>(indptr), gate_idx, (long)n_rows, chunk_counts, chunk_rounds);
+                       static_cast<const int32_t*>(indptr), gate_idx, cg, chunk_counts, chunk_rounds);
   return rg::check_launch("rg_csr_compact_count");
 }
 
 extern "C" int rg_csr_compact_fill(const void* indptr, int32_t indptr_is_i64, const int32_t* gate_idx, int64_t n_rows,
-                                   const int64_t* dict_ptr, const uint8_t* chunk_rounds, int32_t* dict,
-                                   uint16_t* local_idx, rg_stream_t stream) {
+                                   int64_t line_len, int64_t lines_per_plane, const int64_t* dict_ptr,
+                                   const uint8_t* chunk_rounds, int32_t* dict, uint16_t* local_idx, int32_t* error_flag,
+                                   rg_stream_t stream) {
   RG_REQUIRE(n_rows >= 0, RG_EINVAL, "rg_csr_compact_fill: negative size");
   if (n_rows == 0) return RG_OK;
-  RG_REQUIRE(indptr && dict_ptr && chunk_rounds, RG_EINVAL, "rg_csr_compact_fill: null pointer");
-  const long chunks = (n_rows + RG_COMPACT_ROWS - 1) / RG_COMPACT_ROWS;
+  RG_REQUIRE(indptr && dict_ptr && chunk_rounds && error_flag, RG_EINVAL, "rg_csr_compact_fill: null pointer");
+  ChunkGrid cg;
+  RG_REQUIRE(make_chunk_grid(n_rows, line_len, lines_per_plane, &cg), RG_EINVAL,
+             "rg_csr_compact_fill: n_rows=%ld is not planes x lines_per_plane=%ld x line_len=%ld", (long)n_rows,
+             (long)lines_per_plane, (long)line_len);
+  const long chunks = chunk_count(cg);
+  RG_REQUIRE(chunks <= 0x7FFFFFFFL, RG_EUNSUPPORTED, "rg_csr_compact_fill: too many chunks for one launch");
   hipStream_t s = (hipStream_t)stream;
   if (indptr_is_i64)
     hipLaunchKernelGGL(compact_fill_kernel<int64_t>, dim3((unsigned)chunks), dim3(kBuildThreads), 0, s,
-                       static_cast<const int64_t*>(indptr), gate_idx, (long)n_rows, dict_ptr, chunk_rounds, dict, local_idx);
+                       static_cast<const int64_t*>(indptr), gate_idx, cg, dict_ptr, chunk_rounds, dict, local_idx,
+                       error_flag);
   else
     hipLaunchKernelGGL(compact_fill_kernel<int32_t>, dim3((unsigned)chunks), dim3(kBuildThreads), 0, s,
-                       static_cast<const int32_t*>(indptr), gate_idx, (long)n_rows, dict_ptr, chunk_rounds, dict, local_idx);
+                       static_cast<const int32_t*>(indptr), gate_idx, cg, dict_ptr, chunk_rounds, dict, local_idx,
+                       error_flag);
   return rg::check_launch("rg_csr_compact_fill");
 }

@@ -166,9 +166,9 @@ class RoiSearch:
 
 def _build_compact_only(search: "RoiSearch", weighting: str, pairs_per_slab: int = 1_200_000_000):
     """Count -> scan -> per slab of whole grid levels: fill the slab's gate indices into a scratch buffer, derive the
-    dictionaries and 16-bit positions of the 256-row chunks it completes, drop the scratch (the rows of a chunk that
-    straddles the slab boundary are carried into the next slab).  The int32 index array of the whole grid -- half of
-    the standard CSR -- never exists, so a geometry of P pairs needs 6.3*P bytes instead of 8*P (+2.3*P for the copy).
+    dictionaries and 16-bit positions of the slab's chunks (chunks never cross a level), drop the scratch.  The int32
+    index array of the whole grid -- half of the standard CSR -- never exists, so a geometry of P pairs needs about
+    6.2*P bytes instead of 8*P (+2.2*P for the copy).
     Returns ``(DeviceCSR without gate_indices, CompactCSR)`` or ``None`` when a chunk holds more than 65536 distinct
     gates."""
     from .grid_geometry import CompactCSR
@@ -176,7 +176,6 @@ def _build_compact_only(search: "RoiSearch", weighting: str, pairs_per_slab: int
     lib = _native.load_library()
     nz, ny, nx = search.grid_shape
     n_xy = ny * nx
-    rows = _native.RG_COMPACT_ROWS
     n_vox = nz * n_xy
     dev = search.dev
     with torch.cuda.device(dev):
@@ -198,44 +197,32 @@ def _build_compact_only(search: "RoiSearch", weighting: str, pairs_per_slab: int
         local = torch.empty(max(n_pairs, 1), dtype=torch.int16, device=dev)[:n_pairs]
         count_parts, dict_parts = [], []
         max_gate = -1
-        done_row = 0                                              # rows below are compacted; always a chunk boundary
-        carry = torch.empty(0, dtype=torch.int32, device=dev)    # gate indices of rows [done_row, first row of the slab)
         iz0 = 0
         while iz0 < nz:
             iz1 = iz0 + 1
             while iz1 < nz and level_ptr[iz1 + 1] - level_ptr[iz0] <= pairs_per_slab:
                 iz1 += 1
             p0, p1 = int(level_ptr[iz0]), int(level_ptr[iz1])
-            n_carry = int(carry.numel())
-            scratch = torch.empty(max(n_carry + p1 - p0, 1), dtype=torch.int32, device=dev)[:n_carry + p1 - p0]
-            scratch[:n_carry] = carry
+            scratch = torch.empty(max(p1 - p0, 1), dtype=torch.int32, device=dev)[:p1 - p0]
             if p1 > p0:
-                # the fill kernel writes at absolute pair positions: shift the index pointer so that they land behind
-                # the carried rows in the scratch buffer; the weights go straight to their final place
+                # the fill kernel writes at absolute pair positions: shift the index pointer so that the slab's first
+                # pair lands at the start of the scratch buffer; the weights go straight to their final place
                 _native.check(lib.rg_geom_fill_f32(
                     _native.ptr(search.sorted_gates), _native.ptr(search.cell_start), search.cells, _native.ptr(search.xc),
                     _native.ptr(search.yc), _native.ptr(search.zc) + 4 * iz0, iz1 - iz0, ny, nx, search.min_radius,
                     search.beam_factor, _native.WEIGHTINGS[weighting], _native.ptr(indptr) + 8 * iz0 * n_xy,
-                    _native.ptr(scratch) + 4 * n_carry - 4 * p0, _native.ptr(weights), stream), "rg_geom_fill_f32")
-            end_row = n_vox if iz1 == nz else (iz1 * n_xy // rows) * rows
-            if end_row > done_row:
-                ip = indptr[done_row:end_row + 1]
-                q0, q1 = int(ip[0]), int(ip[-1])                  # q0 == p0 - n_carry
-                if q1 > q0:
-                    max_gate = max(max_gate, int(scratch[:q1 - q0].max().item()))
-                built = CompactCSR._rows(ip, _native.ptr(scratch) - 4 * q0, end_row - done_row, _native.ptr(local))
-                if built is None:
-                    return None
-                count_parts.append(built[0])
-                dict_parts.append(built[1])
-                carry = scratch[q1 - q0:].clone()
-                done_row = end_row
-            else:
-                carry = scratch
+                    _native.ptr(scratch) - 4 * p0, _native.ptr(weights), stream), "rg_geom_fill_f32")
+                max_gate = max(max_gate, int(scratch.max().item()))
+            built = CompactCSR._planes(indptr[iz0 * n_xy:iz1 * n_xy + 1], _native.ptr(scratch) - 4 * p0, iz1 - iz0, ny, nx,
+                                       _native.ptr(local))
+            if built is None:
+                return None
+            count_parts.append(built[0])
+            dict_parts.append(built[1])
             del scratch
             iz0 = iz1
         counts_all = torch.cat(count_parts) if count_parts else torch.zeros(0, dtype=torch.int64, device=dev)
-        compact = CompactCSR._finish(indptr, n_vox, local, counts_all, dict_parts)
+        compact = CompactCSR._finish(indptr, search.grid_shape, local, counts_all, dict_parts)
         if n_pairs <= _INT32_MAX:
             indptr = indptr.to(torch.int32)
     return DeviceCSR(indptr, None, weights, max_gate), compact
@@ -266,9 +253,9 @@ def compute_grid_geometry(
 
     ``layout`` (build-specific): ``"csr"`` keeps the reference's three arrays in HBM; ``"auto"`` does so whenever
     they and their compact copy fit the free memory, and otherwise falls to ``"compact"``, which keeps
-    ``indptr``, ``weights`` and the compact copy of the gate indices only (``grid_geometry.CompactCSR``, 6.3 instead
-    of 8 bytes per pair) -- for single-field gridding of geometries too large to hold both; ``.gate_indices`` is then
-    rebuilt from the copy when somebody asks for it.
+    ``indptr``, ``weights`` and the compact copy of the gate indices only (``grid_geometry.CompactCSR``, 6.2 instead
+    of 8 bytes per pair) -- for geometries too large to hold both; ``.gate_indices`` is then rebuilt from the copy
+    when somebody asks for it.
 
     Reference quirks kept on purpose: ``radar_altitude`` is subtracted from ``gate_z``
     in float32 (compute.py:182), the returned geometry does not carry it (compute.py:277-284 => 0.0), and
@@ -289,11 +276,12 @@ def compute_grid_geometry(
     if layout not in ("csr", "compact", "auto"):
         raise ValueError("layout must be 'csr', 'compact' or 'auto'")
     if layout == "auto":
-        # the reference's arrays whenever they fit (8 bytes per pair; their compact copy is added later if there is
-        # room for it), the compact layout alone (6.3 bytes per pair) only for geometries that would not fit otherwise
+        # the reference's arrays whenever they AND their compact copy fit (8 + 2.2 bytes per pair: gridding then runs
+        # through the copy and the int32 index array stays available), the compact layout alone (6.2 bytes per pair)
+        # for geometries where they do not (config 4: 33 G pairs = 266 GB of standard CSR on a 288 GB device)
         n_pairs = search.count_pairs()
         free_b, _ = _native.torch_mod().cuda.mem_get_info(search.dev)
-        layout = "csr" if 8.1 * n_pairs + (10 << 30) <= free_b else "compact"
+        layout = "csr" if 10.4 * n_pairs + (10 << 30) <= free_b else "compact"
         logger.info(f"{n_pairs:,} pairs, {free_b / 1e9:.0f} GB free -> layout '{layout}'")
     if layout == "compact":
         built = _build_compact_only(search, weighting)

@@ -20,6 +20,7 @@ from . import _native
 logger = logging.getLogger("radar_grid.geometry")  # same logger name as the reference (docs/LOGGING.md:128-141)
 
 _INT32_MAX = np.iinfo(np.int32).max
+_NOT_COMPACTABLE = 0x40000000     # chunk_counts marker of rg_csr_compact_count
 
 
 class DeviceCSR:
@@ -42,58 +43,117 @@ class DeviceCSR:
 
 
 class CompactCSR:
-    """Compact device copy of a :class:`DeviceCSR` for ``rg_csr_compact_apply_f32``: rows grouped in chunks of
-    ``RG_COMPACT_ROWS``, each chunk's distinct gates listed once (``dict`` / ``dict_ptr``) and a 16-bit position in
-    that list per pair (``local_idx``).  ``indptr`` and ``weights`` are shared with the standard CSR."""
+    """Compact device copy of a :class:`DeviceCSR` for ``rg_csr_compact_apply_f32``.  Rows are grouped in chunks that
+    cover a 2-D patch of the grid -- segment ``sx`` (rows ``[64*sx, 64*sx+64)`` of a grid line) of
+    ``RG_COMPACT_LINES`` consecutive lines of one plane, chunk number ``(plane*nyg + yg)*nsx + sx`` --, each chunk's
+    distinct gates are listed once (``dict`` / ``dict_ptr``) and every pair stores a 16-bit position in that list
+    (``local_idx``).  A chunk with more than 65536 distinct gates (the patch around the radar on a dense scan) is
+    *split*: one dictionary per wavefront behind a header of ``RG_COMPACT_LINES`` offsets, recognisable by an entry count
+    above 65536.  ``indptr`` and ``weights`` are shared with the standard CSR."""
 
-    __slots__ = ("local_idx", "dict_ptr", "dict", "n_dict", "max_dict", "window_cap")
+    __slots__ = ("local_idx", "dict_ptr", "dict", "n_dict", "max_dict", "window_cap", "grid_shape", "chunk_pairs",
+                 "chunk_counts")
 
-    def __init__(self, local_idx, dict_ptr, dict_, max_dict: int, window_cap: int):
+    def __init__(self, local_idx, dict_ptr, dict_, max_dict: int, window_cap: int, grid_shape, chunk_pairs=None,
+                 chunk_counts=None):
         self.local_idx = local_idx          # int16 storage of the uint16 positions [P]
         self.dict_ptr = dict_ptr            # int64 [chunks + 1]
         self.dict = dict_                   # int32 [D]
         self.n_dict = int(dict_.shape[0])
         self.max_dict = int(max_dict)
-        self.window_cap = int(window_cap)   # LDS window the kernel is launched with (speed only)
+        self.window_cap = int(window_cap)   # LDS window (entries) that covers 99.9 % of the pairs (speed only)
+        self.grid_shape = tuple(int(v) for v in grid_shape)   # (planes, lines per plane, rows per line)
+        self.chunk_pairs = chunk_pairs      # int64 [chunks]: pairs per chunk    } kept to choose the window for a
+        self.chunk_counts = chunk_counts    # int64 [chunks]: distinct gates     } given field count (window_for)
 
     def nbytes(self) -> int:
         return sum(int(t.numel()) * t.element_size() for t in (self.local_idx, self.dict_ptr, self.dict))
 
+    @staticmethod
+    def layout(grid_shape):
+        """``(nsx, nyg, n_chunks)`` of a grid: segments per line, line groups per plane, chunks."""
+        nz, ny, nx = (int(v) for v in grid_shape)
+        nsx = (nx + 63) // 64
+        nyg = (ny + _native.RG_COMPACT_LINES - 1) // _native.RG_COMPACT_LINES
+        return nsx, nyg, nz * nyg * nsx
+
+    @staticmethod
+    def segment_starts(nx: int):
+        """First row of each of a line's ``ceil(nx / 64)`` segments (+ ``nx`` as the last entry).  The segments are
+        balanced -- the first ``nx % nsx`` hold one row more than the others -- exactly as the kernels cut them."""
+        nsx = (int(nx) + 63) // 64
+        base, extra = divmod(int(nx), nsx)
+        return [sx * base + min(sx, extra) for sx in range(nsx + 1)]
+
+    @staticmethod
+    def chunk_of_rows(rows, grid_shape):
+        """Chunk number of every (flat, int64 tensor) row index."""
+        nz, ny, nx = (int(v) for v in grid_shape)
+        nsx, nyg, _ = CompactCSR.layout(grid_shape)
+        base, extra = divmod(nx, nsx)
+        line = rows // nx
+        x = rows - line * nx
+        plane = line // ny
+        y = line - plane * ny
+        split = extra * (base + 1)                  # rows covered by the longer segments
+        sx = (x // (base + 1)).where(x < split, extra + (x - split) // max(base, 1))
+        return (plane * nyg + y // _native.RG_COMPACT_LINES) * nsx + sx
+
+    def window_for(self, n_fields: int, lds_budget_bytes: int = 32768) -> int:
+        """LDS window (entries) for a pass of ``n_fields`` fields: the geometry's 99.9 % window if its entries
+        (4 bytes x stride) fit ``lds_budget_bytes``, else the largest that does."""
+        stride = 1 if n_fields == 1 else 2 if n_fields == 2 else 4 if n_fields <= 4 else 8
+        room = max(0, lds_budget_bytes // (4 * stride)) // 64 * 64
+        return int(min(self.window_cap, room))
+
+    def fallback_fraction(self, window: int) -> float:
+        """Share of the pairs whose chunk holds more distinct gates than ``window`` (they gather per pair)."""
+        if self.chunk_pairs is None or self.chunk_pairs.numel() == 0:
+            return 0.0
+        total = max(int(self.chunk_pairs.sum()), 1)
+        return float(int(self.chunk_pairs[self.chunk_counts > window].sum()) / total)
+
     @classmethod
-    def build(cls, csr: "DeviceCSR") -> Optional["CompactCSR"]:
+    def build(cls, csr: "DeviceCSR", grid_shape) -> Optional["CompactCSR"]:
         """Derive the compact copy on the device (``rg_csr_compact_count`` / ``rg_csr_compact_fill``: one workgroup per
         chunk with an LDS hash set of its gates); ``None`` when a chunk references more than 65536 distinct gates
         (positions are 16 bits; the standard kernel then stays in charge)."""
         torch = _native.torch_mod()
         dev = csr.indptr.device
+        nz, ny, nx = (int(v) for v in grid_shape)
+        if nz * ny * nx != csr.n_vox:
+            raise ValueError(f"grid_shape {grid_shape} does not match the CSR's {csr.n_vox} rows")
         local = torch.empty(max(csr.n_pairs, 1), dtype=torch.int16, device=dev)[:csr.n_pairs]
         with torch.cuda.device(dev):
-            built = cls._rows(csr.indptr, _native.ptr(csr.gate_indices), csr.n_vox, _native.ptr(local))
+            built = cls._planes(csr.indptr, _native.ptr(csr.gate_indices), nz, ny, nx, _native.ptr(local))
         if built is None:
             return None
         counts, dict_ = built
-        return cls._finish(csr.indptr, csr.n_vox, local, counts, [dict_])
+        return cls._finish(csr.indptr, grid_shape, local, counts, [dict_])
 
     @staticmethod
-    def _rows(indptr, gate_idx_ptr: int, n_rows: int, local_ptr: int):
-        """Dictionaries and positions of the chunks of ``n_rows`` rows whose (absolute) row pointers are ``indptr``
-        (a tensor of ``n_rows + 1`` entries, possibly a view into a longer one).  ``gate_idx_ptr`` / ``local_ptr`` are
-        device addresses such that element ``p`` belongs to absolute pair ``p``.  Returns ``(counts int64 [chunks],
-        dict int32)`` with the dictionaries back to back, or ``None`` when a chunk is too rich."""
+    def _planes(indptr, gate_idx_ptr: int, n_planes: int, ny: int, nx: int, local_ptr: int):
+        """Dictionaries and positions of the chunks of ``n_planes`` whole planes whose (absolute) row pointers are
+        ``indptr`` (a tensor of ``n_planes*ny*nx + 1`` entries, possibly a view into a longer one).  ``gate_idx_ptr`` /
+        ``local_ptr`` are device addresses such that element ``p`` belongs to absolute pair ``p``.  Returns
+        ``(counts int64 [chunks], dict int32)`` with the dictionaries back to back, or ``None`` when a chunk is too
+        rich."""
         torch = _native.torch_mod()
         lib = _native.load_library()
-        rows = _native.RG_COMPACT_ROWS
         dev = indptr.device
-        n_chunks = (n_rows + rows - 1) // rows
+        n_rows = n_planes * ny * nx
+        n_chunks = int(lib.rg_csr_compact_chunks(n_rows, nx, ny)) if n_rows else 0
+        if n_chunks < 0:
+            raise _native.NativeError("rg_csr_compact_chunks rejected the grid shape")
         if n_chunks == 0:
             return torch.zeros(0, dtype=torch.int64, device=dev), torch.zeros(0, dtype=torch.int32, device=dev)
         is_i64 = int(indptr.dtype == torch.int64)
         stream = _native.stream_ptr()
         counts = torch.zeros(n_chunks + 1, dtype=torch.int32, device=dev)
         rounds = torch.empty(n_chunks, dtype=torch.uint8, device=dev)
-        _native.check(lib.rg_csr_compact_count(_native.ptr(indptr), is_i64, gate_idx_ptr, n_rows, _native.ptr(counts),
-                                               _native.ptr(rounds), stream), "rg_csr_compact_count")
-        if int(counts.max()) > 65536:
+        _native.check(lib.rg_csr_compact_count(_native.ptr(indptr), is_i64, gate_idx_ptr, n_rows, nx, ny,
+                                               _native.ptr(counts), _native.ptr(rounds), stream), "rg_csr_compact_count")
+        if int(counts.max()) >= _NOT_COMPACTABLE:      # a single 64-row segment references more than 65536 gates
             return None
         dict_ptr = torch.empty(n_chunks + 1, dtype=torch.int64, device=dev)
         ws_bytes = int(lib.rg_scan_workspace_bytes(n_chunks))
@@ -102,53 +162,76 @@ class CompactCSR:
                                              stream), "rg_scan_counts_i64")
         n_dict = int(dict_ptr[-1])
         dict_ = torch.empty(max(n_dict, 1), dtype=torch.int32, device=dev)[:n_dict]
-        _native.check(lib.rg_csr_compact_fill(_native.ptr(indptr), is_i64, gate_idx_ptr, n_rows, _native.ptr(dict_ptr),
-                                              _native.ptr(rounds), _native.ptr(dict_), local_ptr, stream),
-                      "rg_csr_compact_fill")
+        err = torch.zeros(1, dtype=torch.int32, device=dev)
+        _native.check(lib.rg_csr_compact_fill(_native.ptr(indptr), is_i64, gate_idx_ptr, n_rows, nx, ny,
+                                              _native.ptr(dict_ptr), _native.ptr(rounds), _native.ptr(dict_), local_ptr,
+                                              _native.ptr(err), stream), "rg_csr_compact_fill")
+        flag = int(err.item())
+        if flag:
+            raise _native.NativeError(f"rg_csr_compact_fill: the fill pass saw different inputs than the count pass "
+                                      f"(flag {flag}); were the gate indices modified during the build?")
         return counts[:n_chunks].to(torch.int64), dict_
 
     @classmethod
-    def _finish(cls, indptr, n_vox: int, local, counts, parts) -> "CompactCSR":
+    def _finish(cls, indptr, grid_shape, local, counts, parts) -> "CompactCSR":
         torch = _native.torch_mod()
-        rows = _native.RG_COMPACT_ROWS
+        lines = _native.RG_COMPACT_LINES
         dev = counts.device
-        n_chunks = int(counts.shape[0])
+        nz, ny, nx = (int(v) for v in grid_shape)
+        nsx, nyg, n_chunks = cls.layout(grid_shape)
+        assert n_chunks == int(counts.shape[0])
         dict_ptr = torch.zeros(n_chunks + 1, dtype=torch.int64, device=dev)
         dict_ptr[1:] = torch.cumsum(counts, 0)
         dict_ = torch.cat(parts) if parts else torch.zeros(1, dtype=torch.int32, device=dev)[:0]
-        # LDS window: the smallest size that leaves at most 0.1 % of the pairs to the per-pair fallback
-        bounds = torch.clamp(torch.arange(n_chunks + 1, device=dev, dtype=torch.int64) * rows, max=n_vox)
-        edges = indptr[bounds].to(torch.int64)
-        chunk_pairs = edges[1:] - edges[:-1]
+        # pairs per chunk: per (line, segment) from the row pointers, summed over the lines of a group
+        if n_chunks:
+            seg_x = torch.tensor(cls.segment_starts(nx), device=dev, dtype=torch.int64)
+            line0 = torch.arange(nz * ny, device=dev, dtype=torch.int64) * nx
+            edges = indptr[(line0[:, None] + seg_x[None, :]).reshape(-1)].to(torch.int64).view(nz * ny, nsx + 1)
+            seg_pairs = (edges[:, 1:] - edges[:, :-1]).view(nz, ny, nsx)
+            pad = nyg * lines - ny
+            if pad:
+                seg_pairs = torch.cat([seg_pairs, torch.zeros((nz, pad, nsx), dtype=torch.int64, device=dev)], dim=1)
+            chunk_pairs = seg_pairs.view(nz, nyg, lines, nsx).sum(dim=2).reshape(-1)
+        else:
+            chunk_pairs = torch.zeros(0, dtype=torch.int64, device=dev)
+        # LDS window: the smallest size (multiple of 256 entries) that leaves at most 0.1 % of the pairs to the
+        # per-pair fallback
         window_cap = _native.RG_COMPACT_MAX_WINDOW
-        total = max(int(chunk_pairs.sum()), 1)
-        for cap in (1024, 2048, 4096, 8192):
+        total = max(int(chunk_pairs.sum()), 1) if n_chunks else 1
+        for cap in range(256, _native.RG_COMPACT_MAX_WINDOW + 1, 256):
             if int(chunk_pairs[counts > cap].sum()) <= total // 1000:
                 window_cap = cap
                 break
-        return cls(local, dict_ptr, dict_, int(counts.max()) if n_chunks else 0, window_cap)
+        return cls(local, dict_ptr, dict_, int(counts.max()) if n_chunks else 0, window_cap, grid_shape,
+                   chunk_pairs, counts)
 
-    def decode(self, csr: "DeviceCSR", row0: int = 0, row1: Optional[int] = None, chunks_per_slab: int = 8192):
+    def decode(self, csr: "DeviceCSR", row0: int = 0, row1: Optional[int] = None, rows_per_slab: int = 2_000_000):
         """The standard int32 gate indices of rows ``[row0, row1)`` (default: all), rebuilt from positions and
         dictionaries; device tensor of ``indptr[row1] - indptr[row0]`` entries."""
         torch = _native.torch_mod()
-        rows = _native.RG_COMPACT_ROWS
         dev = csr.indptr.device
         row1 = csr.n_vox if row1 is None else row1
         q0, q1 = int(csr.indptr[row0]), int(csr.indptr[row1])
         out = torch.empty(max(q1 - q0, 1), dtype=torch.int32, device=dev)[:q1 - q0]
-        c_lo, c_hi = row0 // rows, (row1 + rows - 1) // rows
-        for c0 in range(c_lo, c_hi, chunks_per_slab):
-            c1 = min(c_hi, c0 + chunks_per_slab)
-            r0, r1 = max(c0 * rows, row0), min(csr.n_vox, c1 * rows, row1)
+        for r0 in range(row0, row1, rows_per_slab):
+            r1 = min(row1, r0 + rows_per_slab)
             ip = csr.indptr[r0:r1 + 1].to(torch.int64)
             p0, p1 = int(ip[0]), int(ip[-1])
             if p1 == p0:
                 continue
-            chunk_of_row = torch.arange(r0, r1, device=dev, dtype=torch.int64) // rows
-            chunk_of_pair = torch.repeat_interleave(chunk_of_row, ip[1:] - ip[:-1], output_size=p1 - p0)
+            rows = torch.arange(r0, r1, device=dev, dtype=torch.int64)
+            chunk_of_row = self.chunk_of_rows(rows, self.grid_shape)
+            start_of_row = self.dict_ptr[chunk_of_row]
+            # split chunks (more than 65536 entries: one dictionary per wavefront behind a header of offsets)
+            is_split = (self.dict_ptr[chunk_of_row + 1] - start_of_row) > 65536
+            if bool(is_split.any()):
+                wave = ((rows // self.grid_shape[2]) % self.grid_shape[1]) % _native.RG_COMPACT_LINES
+                header = self.dict[(start_of_row + wave).clamp(max=self.n_dict - 1)].to(torch.int64)
+                start_of_row = start_of_row + torch.where(is_split, header, torch.zeros_like(header))
+            start_of_pair = torch.repeat_interleave(start_of_row, ip[1:] - ip[:-1], output_size=p1 - p0)
             pos = self.local_idx[p0:p1].to(torch.int64) & 0xFFFF
-            out[p0 - q0:p1 - q0] = self.dict[self.dict_ptr[chunk_of_pair] + pos]
+            out[p0 - q0:p1 - q0] = self.dict[start_of_pair + pos]
         return out
 
 
@@ -217,7 +300,7 @@ class GridGeometry:
         self._dev = None
         self.__dict__.pop("_compact", None)
         self.__dict__.pop("_gridders", None)
-        self.__dict__.pop("_single_field_passes", None)
+        self.__dict__.pop("_passes", None)
 
     @property
     def indptr(self) -> np.ndarray:
@@ -303,7 +386,7 @@ class GridGeometry:
         cached = getattr(self, "_compact", None)
         if cached is not None and cached[0] is csr:
             return cached[1]
-        compact = CompactCSR.build(csr)
+        compact = CompactCSR.build(csr, self.grid_shape)
         self._compact = (csr, compact)
         if compact is not None:
             logger.info(f"Compact CSR copy: {compact.nbytes() / 1e6:.1f} MB, {compact.n_dict:,} dictionary entries, "

@@ -12,9 +12,9 @@ Two layers:
 
 All fields handed to one call are gridded by ONE pass over the CSR (the reference re-reads the CSR per field,
 interpolate.py:137-140): the mask of every field is folded into its values and the fields are interleaved
-gate-major, so each (voxel, gate) pair costs a single gather.  Single-field passes over a large geometry switch, from
-the second use of that geometry on, to a compact device copy of the CSR (``rg_csr_compact_apply_f32``: 16-bit
-positions in a per-chunk gate dictionary, field window in LDS) -- identical results, about 25 % less time.
+gate-major, so each (voxel, gate) pair costs a single gather.  Passes over a large geometry switch, from the second use
+of that geometry on, to a compact device copy of the CSR (``rg_csr_compact_apply_f32``: 16-bit positions in a per-chunk
+gate dictionary, the chunk's field values staged in LDS) -- identical results, 25-40 % less time.
 """
 from __future__ import annotations
 
@@ -69,9 +69,12 @@ class CsrGridder:
     or graph-capture them.  All launches go to torch's current stream.
     """
 
-    def __init__(self, geometry: GridGeometry, n_gates: int, n_fields: int, device=None, compact: bool = False):
-        """``compact``: for single-field passes use the compact device copy of the CSR (``rg_csr_compact_apply_f32``,
-        built and cached on the geometry the first time) when the geometry allows one; results are identical."""
+    def __init__(self, geometry: GridGeometry, n_gates: int, n_fields: int, device=None, compact: bool = False,
+                 tile: int = 0):
+        """``compact``: run the pass through the compact device copy of the CSR (``rg_csr_compact_apply_f32``, built
+        and cached on the geometry the first time) when the geometry allows one and its LDS window for this field count
+        covers (nearly) all pairs; results are identical, bit for bit.  ``tile``: diagnostic override of the pipeline
+        tile (0 = default; non-default values change the order of the float32 adds)."""
         torch = _native.torch_mod()
         self.lib = _native.load_library()
         if not 1 <= n_fields <= _native.RG_MAX_FIELDS:
@@ -81,22 +84,28 @@ class CsrGridder:
         self.n_gates = int(n_gates)
         self.n_fields = int(n_fields)
         self.stride = _stride_for(n_fields)
+        self.tile = int(tile)
         self.grid_shape = tuple(int(s) for s in geometry.grid_shape)
         self.n_vox = int(np.prod(self.grid_shape))
+        if self.n_vox != self.csr.n_vox:
+            raise ValueError(f"grid_shape {self.grid_shape} does not match the geometry's {self.csr.n_vox} rows")
         if self.csr.max_gate >= self.n_gates:
             # the reference's fancy index (interpolate.py:74) raises the same way
             raise IndexError(f"index {self.csr.max_gate} is out of bounds for axis 0 with size {self.n_gates}")
         self.packed = torch.empty(max(self.n_gates, 1) * self.stride, dtype=torch.float32, device=self.dev)
         compact_only = self.csr.gate_indices is None
-        if compact_only and self.n_fields != 1:
-            raise _native.NativeError("this geometry holds only the compact copy of its CSR, which serves single-field "
-                                      "passes; build it with compute_grid_geometry() for fused multi-field passes")
-        self.compact = (geometry.device_compact(self.dev)
-                        if ((compact or compact_only) and self.n_fields == 1 and self.csr.n_pairs) else None)
-        if self.compact is not None and not compact_only and self.compact.window_cap > _COMPACT_MAX_USEFUL_WINDOW:
-            # chunks with this many distinct gates (dense scans on coarse grids) leave too little LDS for occupancy:
-            # measured slower than the standard kernel (config 4: 52.8 vs 49.1 ms)
-            self.compact = None
+        # Measured (config 2 / bench grid, ms per pass, standard vs compact kernel): 1 field 1.81 / 1.28 and 13.1 / 9.5,
+        # 2 fields 1.80 / 1.85 and 14.9 / 13.0, 3 fields 2.60 / 3.45 and 18.8 / 20.7, 4 fields 2.89 / 3.71 and 20.7 /
+        # 22.5: from 3 fields on the 16-byte window entries and the 32-byte tile entries leave the compact kernel two or
+        # three workgroups per CU, and the standard kernel -- no window -- wins.  A compact-only geometry has no choice.
+        want = (compact and self.n_fields <= _COMPACT_MAX_FIELDS) or compact_only
+        self.compact = geometry.device_compact(self.dev) if (want and self.csr.n_pairs) else None
+        self.window = 0
+        if self.compact is not None:
+            self.window = self.compact.window_for(self.n_fields)
+            if not compact_only and self.compact.fallback_fraction(self.window) > _COMPACT_MAX_FALLBACK:
+                # too many chunks would gather per pair (dense scans next to many fields): the standard kernel is faster
+                self.compact, self.window = None, 0
 
     def _check_fields(self, fields, masks, shared_mask):
         torch = _native.torch_mod()
@@ -125,20 +134,22 @@ class CsrGridder:
                                                   _native.ptr(self.packed), _native.stream_ptr()), "rg_pack_fields_f32")
 
     def apply(self, out, fill_value: float = np.nan) -> None:
-        """``rg_csr_apply_f32``: one pass over the CSR for all packed fields -> ``out[F, n_vox]``."""
+        """One pass over the CSR for all packed fields -> ``out[F, n_vox]`` (``rg_csr_compact_apply_f32`` through the
+        compact copy, ``rg_csr_apply_f32`` otherwise)."""
         csr = self.csr
+        nz, ny, nx = self.grid_shape
         if self.compact is not None:
             c = self.compact
             _native.check(self.lib.rg_csr_compact_apply_f32(
                 _native.ptr(csr.indptr), int(csr.is_i64), _native.ptr(c.local_idx), _native.ptr(csr.weights),
-                _native.ptr(c.dict_ptr), _native.ptr(c.dict), self.n_vox, csr.n_pairs, _native.ptr(self.packed),
-                self.n_gates, float(np.float32(fill_value)), _native.ptr(out), c.window_cap, 0, _native.stream_ptr()),
-                "rg_csr_compact_apply_f32")
+                _native.ptr(c.dict_ptr), _native.ptr(c.dict), self.n_vox, csr.n_pairs, nx, ny, _native.ptr(self.packed),
+                self.n_fields, self.stride, self.n_gates, float(np.float32(fill_value)), _native.ptr(out), self.window,
+                self.tile, _native.stream_ptr()), "rg_csr_compact_apply_f32")
             return
-        _native.check(self.lib.rg_csr_apply_f32(
+        _native.check(self.lib.rg_csr_apply_f32_ex(
             _native.ptr(csr.indptr), int(csr.is_i64), _native.ptr(csr.gate_indices), _native.ptr(csr.weights),
-            self.n_vox, csr.n_pairs, _native.ptr(self.packed), self.n_fields, self.stride, self.n_gates,
-            float(np.float32(fill_value)), _native.ptr(out), _native.stream_ptr()), "rg_csr_apply_f32")
+            self.n_vox, csr.n_pairs, nx, _native.ptr(self.packed), self.n_fields, self.stride, self.n_gates,
+            float(np.float32(fill_value)), _native.ptr(out), self.tile, _native.stream_ptr()), "rg_csr_apply_f32")
 
     def algorithmic_bytes(self) -> int:
         """Bytes one ``apply`` launch must move: index + weight per pair, the row pointers,
@@ -149,28 +160,30 @@ class CsrGridder:
 
     def compact_bytes(self) -> Optional[int]:
         """Bytes one launch of the compact kernel must move: 16-bit position + weight per pair, the dictionaries and
-        their offsets, the row pointers, the field once, the grid once (``None`` without a compact copy)."""
+        their offsets, the row pointers, every field once, every grid once (``None`` without a compact copy)."""
         if self.compact is None:
             return None
         csr, c = self.csr, self.compact
         ip = 8 if csr.is_i64 else 4
         return (6 * csr.n_pairs + 4 * c.n_dict + 8 * int(c.dict_ptr.numel()) + ip * (self.n_vox + 1)
-                + 5 * self.n_gates + 4 * self.n_vox)
+                + self.n_fields * (5 * self.n_gates + 4 * self.n_vox))
 
 
 _COMPACT_MIN_PAIRS = 50_000_000     # below this a pass takes well under a millisecond either way
-_COMPACT_MAX_USEFUL_WINDOW = 4096   # LDS window (values) beyond which the compact kernel loses to the standard one
+_COMPACT_MAX_FIELDS = 2            # fused passes of more fields run the standard kernel (see CsrGridder.__init__)
+_COMPACT_MAX_FALLBACK = 0.02        # share of pairs allowed on the per-pair path before the standard kernel is preferred
 
 
 def _use_compact(geometry: GridGeometry, dev) -> bool:
-    """Policy for single-field passes: the compact copy of the CSR costs a one-time conversion (about 15 ms per
-    1e9 pairs) and 2.3 bytes per pair of HBM, so it is built the SECOND time a geometry grids a single field, when
-    the geometry is large enough to matter and the memory is there; once built it is always used."""
+    """Policy of ``grid_fields_device`` / ``apply_geometry``: the compact copy of the CSR costs a one-time conversion
+    (about 15 ms per 1e9 pairs) and 2.2 bytes per pair of HBM, so it is built the SECOND time a geometry grids
+    something, when the geometry is large enough to matter and the memory is there; once built it is always used.
+    ``GridGeometry.device_compact()`` builds it explicitly ahead of time."""
     cached = getattr(geometry, "_compact", None)
     if cached is not None and cached[0] is geometry.device_csr(dev):
         return cached[1] is not None
-    uses = getattr(geometry, "_single_field_passes", 0) + 1
-    geometry._single_field_passes = uses
+    uses = getattr(geometry, "_passes", 0) + 1
+    geometry._passes = uses
     n_pairs = geometry.device_csr(dev).n_pairs
     if uses < 2 or n_pairs < _COMPACT_MIN_PAIRS:
         return False
@@ -228,7 +241,7 @@ def grid_fields_device(geometry: GridGeometry, fields: Sequence, masks: Optional
         for f0 in range(0, n_fields, _native.RG_MAX_FIELDS):
             f1 = min(n_fields, f0 + _native.RG_MAX_FIELDS)
             gridder = _cached_gridder(geometry, n_gates, f1 - f0, dev,
-                                      compact=n_fields == 1 and _use_compact(geometry, dev))
+                                      compact=_use_compact(geometry, dev))
             gridder.pack(fields[f0:f1], masks[f0:f1], shared_mask)
             gridder.apply(out.view(n_fields, n_vox)[f0:f1], fill_value)
     return out.view(n_fields, nz, ny, nx)

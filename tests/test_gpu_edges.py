@@ -214,9 +214,10 @@ def test_argument_validation_on_the_device_layer(rg):
 
 @pytest.mark.parametrize("shape", [(1, 1, 1), (1, 3, 255), (2, 1, 257), (1, 5, 512), (3, 7, 300)])
 def test_compact_csr_edge_shapes(rg, tmp_path, shape):
-    """Compact copy on grids that are not a multiple of the 256-row chunk (a chunk then spans several y-rows or
-    levels), with int32 and int64 row pointers, empty rows and a custom fill value: bit-identical to the standard
-    kernel, both with the LDS window and on the per-pair fallback."""
+    """Compact copy on grids whose lines are not a multiple of 64 rows and whose planes are not a multiple of 4 lines
+    (short segments, chunks with fewer than 4 live wavefronts), with int32 and int64 row pointers, empty rows and a
+    custom fill value: bit-identical to the standard kernel for 1-8 fused fields, both with the LDS window and on the
+    per-pair fallback."""
     import torch
     from radar_processor_amd import _native
     from radar_processor_amd.gridding import CsrGridder
@@ -248,18 +249,45 @@ def test_compact_csr_edge_shapes(rg, tmp_path, shape):
         g_c.apply(got, fill_value=-1.0)
         assert torch.equal(got.view(torch.int32), want.view(torch.int32))
         c, k = g_c.compact, g_c.csr
+        assert torch.equal(c.decode(k), k.gate_indices)
         lib = _native.load_library()
-        _native.check(lib.rg_csr_compact_apply_f32(
-            _native.ptr(k.indptr), int(k.is_i64), _native.ptr(c.local_idx), _native.ptr(k.weights), _native.ptr(c.dict_ptr),
-            _native.ptr(c.dict), g_c.n_vox, k.n_pairs, _native.ptr(g_c.packed), g_c.n_gates, -1.0, _native.ptr(got), 0, 0,
-            _native.stream_ptr()), "rg_csr_compact_apply_f32")
+
+        def compact_apply(gr, out, window, tile):
+            _native.check(lib.rg_csr_compact_apply_f32(
+                _native.ptr(k.indptr), int(k.is_i64), _native.ptr(c.local_idx), _native.ptr(k.weights),
+                _native.ptr(c.dict_ptr), _native.ptr(c.dict), gr.n_vox, k.n_pairs, nx, ny, _native.ptr(gr.packed),
+                gr.n_fields, gr.stride, gr.n_gates, -1.0, _native.ptr(out), window, tile, _native.stream_ptr()),
+                "rg_csr_compact_apply_f32")
+
+        compact_apply(g_c, got, 0, 0)
         assert torch.equal(got.view(torch.int32), want.view(torch.int32))     # per-pair fallback, same tile size
-        _native.check(lib.rg_csr_compact_apply_f32(
-            _native.ptr(k.indptr), int(k.is_i64), _native.ptr(c.local_idx), _native.ptr(k.weights), _native.ptr(c.dict_ptr),
-            _native.ptr(c.dict), g_c.n_vox, k.n_pairs, _native.ptr(g_c.packed), g_c.n_gates, -1.0, _native.ptr(got),
-            c.window_cap, 256, _native.stream_ptr()), "rg_csr_compact_apply_f32")
-        # another tile size regroups the float32 partial sums: equal to rounding, not bit for bit
+        compact_apply(g_c, got, c.window_cap, 256)
+        # another tile size regroups the float32 partial sums: equal to rounding, not bit for bit -- but equal, bit for
+        # bit, to the standard kernel run with the same tile
         np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=2e-6, atol=1e-5)
+        g_t = CsrGridder(g2, f.numel(), 1, device=dev, tile=256)
+        g_t.pack([f], [m])
+        want_t = torch.empty_like(want)
+        g_t.apply(want_t, fill_value=-1.0)
+        assert torch.equal(got.view(torch.int32), want_t.view(torch.int32))
+        # fused multi-field passes through the compact copy: every stride, windowed and per-pair paths, bit for bit
+        extra = [torch.from_numpy(np.roll(val, 7 * (i + 1)) * np.float32(1.0 + i)).to(dev) for i in range(7)]
+        emask = [torch.from_numpy(np.roll(mask, 13 * (i + 1)).astype(np.uint8)).to(dev) if i % 2 else None for i in range(7)]
+        for nf in (2, 3, 4, 5, 8):
+            fl, ml = [f] + extra[:nf - 1], [m] + emask[:nf - 1]
+            gm_c = CsrGridder(g2, f.numel(), nf, device=dev, compact=True)
+            gm_s = CsrGridder(g2, f.numel(), nf, device=dev)
+            assert gm_s.compact is None
+            gm_c.compact, gm_c.window = c, c.window_for(nf)   # even if the policy would have preferred the standard kernel
+            gm_c.pack(fl, ml); gm_s.pack(fl, ml)
+            want_m = torch.empty((nf, gm_s.n_vox), dtype=torch.float32, device=dev)
+            got_m = torch.full_like(want_m, 3.0)
+            gm_s.apply(want_m, fill_value=-1.0)
+            gm_c.apply(got_m, fill_value=-1.0)
+            assert torch.equal(got_m.view(torch.int32), want_m.view(torch.int32)), nf
+            got_m.fill_(3.0)
+            compact_apply(gm_c, got_m, 0, 0)
+            assert torch.equal(got_m.view(torch.int32), want_m.view(torch.int32)), nf
 
 
 def test_compact_csr_rich_chunks(rg):
@@ -272,7 +300,7 @@ def test_compact_csr_rich_chunks(rg):
     from radar_processor_amd.grid_geometry import CompactCSR, DeviceCSR, GridGeometry
     dev = torch.device("cuda")
     gen = torch.Generator(device=dev).manual_seed(5)
-    n_gates, n_rows = 300_000, 1000                      # 4 chunks, the last one partial (232 rows)
+    n_gates, n_rows = 300_000, 1000                      # 4 lines of 250 rows = one chunk group of 4 segments each
     lengths = torch.randint(150, 260, (n_rows,), device=dev, generator=gen)
     lengths[17] = 0
     lengths[300:310] = 0
@@ -282,7 +310,7 @@ def test_compact_csr_rich_chunks(rg):
     gidx = torch.randint(0, n_gates, (n_pairs,), device=dev, generator=gen, dtype=torch.int32)
     gidx[:5000] = gidx[0]                                # plus one heavily repeated gate
     wts = torch.rand(n_pairs, device=dev, generator=gen) + 0.01
-    shape, limits = (1, 1, n_rows), ((0.0, 0.0), (0.0, 0.0), (0.0, 1.0))
+    shape, limits = (1, 4, n_rows // 4), ((0.0, 0.0), (0.0, 1.0), (0.0, 1.0))
     csr = DeviceCSR(indptr.to(torch.int32), gidx, wts, int(gidx.max()))
     geom = GridGeometry.from_device(shape, limits, csr, 17000.0)
     compact = geom.device_compact(dev)
@@ -291,15 +319,42 @@ def test_compact_csr_rich_chunks(rg):
     values = torch.randn(n_gates, device=dev, generator=gen)
     mask = (torch.rand(n_gates, device=dev, generator=gen) < 0.2).to(torch.uint8)
     g_c = CsrGridder(geom, n_gates, 1, device=dev)
-    g_c.compact = compact                                # force the copy although its window is past the useful size
+    g_c.compact, g_c.window = compact, 8192              # force the copy although hardly any chunk fits its window
     g_s = CsrGridder(geom, n_gates, 1, device=dev)
     g_c.pack([values], [mask]); g_s.pack([values], [mask])
     want = torch.empty((1, n_rows), dtype=torch.float32, device=dev)
     got = torch.empty_like(want)
     g_s.apply(want); g_c.apply(got)
     assert torch.equal(got.view(torch.int32), want.view(torch.int32))
-    # more than 65536 distinct gates in one chunk: not compactable
+    # more than 65536 distinct gates in one chunk (76 800 here) but fewer in each of its four segments: the chunk is
+    # stored SPLIT -- one dictionary per wavefront behind a header -- and still decodes and grids bit for bit
     rich = torch.arange(256 * 300, device=dev, dtype=torch.int32)
+    rich = rich[torch.randperm(rich.numel(), device=dev, generator=gen)].contiguous()
     ip2 = torch.arange(0, 256 * 300 + 1, 300, device=dev, dtype=torch.int64)
-    csr2 = DeviceCSR(ip2.to(torch.int32), rich, torch.ones(rich.numel(), device=dev), int(rich.max()))
-    assert CompactCSR.build(csr2) is None
+    csr2 = DeviceCSR(ip2.to(torch.int32), rich, torch.rand(rich.numel(), device=dev, generator=gen) + 0.01, int(rich.max()))
+    split = CompactCSR.build(csr2, (1, 4, 64))
+    assert split is not None and split.max_dict == 4 + 76800 and split.dict_ptr.tolist() == [0, 4 + 76800]
+    assert split.dict[:4].tolist() == [4, 4 + 19200, 4 + 38400, 4 + 57600]
+    assert torch.equal(split.decode(csr2), rich)
+    assert torch.equal(split.decode(csr2, 70, 200), rich[70 * 300:200 * 300])
+    geom2 = GridGeometry.from_device((1, 4, 64), limits, csr2, 17000.0, compact=split)
+    vals2 = torch.randn(76800, device=dev, generator=gen)
+    mask2 = (torch.rand(76800, device=dev, generator=gen) < 0.3).to(torch.uint8)
+    for nf in (1, 3):
+        g_c2 = CsrGridder(geom2, 76800, nf, device=dev)
+        g_c2.compact, g_c2.window = split, split.window_for(nf)
+        g_s2 = CsrGridder(geom2, 76800, nf, device=dev)
+        assert g_s2.compact is None
+        fl = [vals2, vals2 * 2.0, -vals2][:nf]
+        g_c2.pack(fl, [mask2] * nf); g_s2.pack(fl, [mask2] * nf)
+        want2 = torch.empty((nf, 256), dtype=torch.float32, device=dev)
+        got2 = torch.full_like(want2, 5.0)
+        g_s2.apply(want2); g_c2.apply(got2)
+        assert torch.equal(got2.view(torch.int32), want2.view(torch.int32)), nf
+    four = CompactCSR.build(csr2, (4, 1, 64))                   # the same rows as four one-line chunks: 19 200 gates each
+    assert four is not None and four.max_dict == 19200 and torch.equal(four.decode(csr2), rich)
+    # a single 64-row segment with more than 65536 distinct gates: not compactable, the standard kernel stays in charge
+    big = torch.arange(64 * 1100, device=dev, dtype=torch.int32)
+    ip3 = torch.arange(0, 64 * 1100 + 1, 1100, device=dev, dtype=torch.int64)
+    csr3 = DeviceCSR(ip3.to(torch.int32), big, torch.ones(big.numel(), device=dev), int(big.max()))
+    assert CompactCSR.build(csr3, (1, 1, 64)) is None

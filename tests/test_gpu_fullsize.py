@@ -173,71 +173,101 @@ def test_c2_compact_csr_is_bit_identical(c2):
     """rg_csr_compact_apply_f32 (16-bit dictionary positions, LDS field window) against rg_csr_apply_f32 on the full
     config-2 geometry: the dictionaries reproduce the gate indices exactly and the grids agree bit for bit -- with the
     geometry's own window size, with a window too small for most chunks, and with no window at all (every chunk on
-    the per-pair fallback)."""
+    the per-pair fallback); one field and the fused three-field pass of config 3."""
     from radar_processor_amd import _native
+    from radar_processor_amd.grid_geometry import CompactCSR
     from radar_processor_amd.gridding import CsrGridder
     rg, torch, geom, dev = c2["rg"], c2["torch"], c2["geom"], c2["dev"]
+    nz, ny, nx = c2["cfg"]["grid_shape"]
     f, m = c2["fields"]["DBZH"], c2["masks"]["DBZH"]
     g_c = CsrGridder(geom, f.numel(), 1, device=dev, compact=True)
     g_s = CsrGridder(geom, f.numel(), 1, device=dev)
     assert g_c.compact is not None and g_s.compact is None
     csr, c = g_c.csr, g_c.compact
     assert c.local_idx.numel() == csr.n_pairs and int(c.dict_ptr[-1]) == c.n_dict
-    assert g_c.compact_bytes() < 0.85 * g_c.algorithmic_bytes()
+    assert c.dict_ptr.numel() == CompactCSR.layout((nz, ny, nx))[2] + 1
+    assert g_c.compact_bytes() < 0.82 * g_c.algorithmic_bytes()
+    assert c.window_cap <= 2048 and c.fallback_fraction(c.window_cap) <= 1e-3    # 4 x 64 patches: small dictionaries
     # decode a sample of pairs: dict[dict_ptr[chunk(row)] + position] == gate index
     ip = csr.indptr.to(torch.int64)
     rows = torch.randint(0, csr.n_vox, (20000,), device=dev)
     rows = rows[(ip[rows + 1] - ip[rows]) > 0]
     pairs = ip[rows] + (torch.rand(rows.numel(), device=dev) * (ip[rows + 1] - ip[rows]).float()).long()
     pos = c.local_idx[pairs].to(torch.int64) & 0xFFFF
-    decoded = c.dict[c.dict_ptr[rows // _native.RG_COMPACT_ROWS] + pos]
+    decoded = c.dict[c.dict_ptr[CompactCSR.chunk_of_rows(rows, (nz, ny, nx))] + pos]
     assert bool((decoded == csr.gate_indices[pairs]).all())
-    # the dictionaries hold every chunk's distinct gates exactly once (checked against torch.unique on 4096 chunks)
-    rows_per = _native.RG_COMPACT_ROWS
-    c0, c1 = 30000, 34096
-    ipw = ip[c0 * rows_per:c1 * rows_per + 1]
-    chunk_of_pair = torch.repeat_interleave(torch.arange(c0 * rows_per, c1 * rows_per, device=dev) // rows_per,
-                                            ipw[1:] - ipw[:-1])
+    # the dictionaries hold every chunk's distinct gates exactly once (checked against torch.unique on 40 whole lines)
+    r_lo, r_hi = (7 * ny + 480) * nx, (7 * ny + 520) * nx
+    ipw = ip[r_lo:r_hi + 1]
+    chunk_of_row = CompactCSR.chunk_of_rows(torch.arange(r_lo, r_hi, device=dev), (nz, ny, nx))
+    chunk_of_pair = torch.repeat_interleave(chunk_of_row, ipw[1:] - ipw[:-1])
     keys = (chunk_of_pair << 32) | csr.gate_indices[int(ipw[0]):int(ipw[-1])].to(torch.int64)
     want_keys = torch.unique(keys)
-    d0, d1 = int(c.dict_ptr[c0]), int(c.dict_ptr[c1])
-    chunk_of_entry = torch.repeat_interleave(torch.arange(c0, c1, device=dev), c.dict_ptr[c0 + 1:c1 + 1] - c.dict_ptr[c0:c1])
-    got_keys = torch.sort((chunk_of_entry << 32) | c.dict[d0:d1].to(torch.int64)).values
-    assert bool(torch.equal(got_keys, want_keys))
+    chunks = torch.unique(chunk_of_row)
+    got_keys = torch.cat([(ch << 32) | c.dict[int(c.dict_ptr[ch]):int(c.dict_ptr[ch + 1])].to(torch.int64)
+                          for ch in chunks[::7]])
+    want_sub = want_keys[torch.isin(want_keys >> 32, chunks[::7])]
+    assert bool(torch.equal(torch.sort(got_keys).values, want_sub))
     # grids
     g_c.pack([f], [m]); g_s.pack([f], [m])
     want = torch.empty((1, g_s.n_vox), dtype=torch.float32, device=dev)
     g_s.apply(want)
     lib = _native.load_library()
-    for cap in (c.window_cap, 1024, 0):
-        got = torch.full_like(want, -7.0)
+
+    def compact_apply(gr, out, window):
         _native.check(lib.rg_csr_compact_apply_f32(
             _native.ptr(csr.indptr), int(csr.is_i64), _native.ptr(c.local_idx), _native.ptr(csr.weights),
-            _native.ptr(c.dict_ptr), _native.ptr(c.dict), g_c.n_vox, csr.n_pairs, _native.ptr(g_c.packed), g_c.n_gates,
-            float("nan"), _native.ptr(got), cap, 0, _native.stream_ptr()), "rg_csr_compact_apply_f32")
+            _native.ptr(c.dict_ptr), _native.ptr(c.dict), gr.n_vox, csr.n_pairs, nx, ny, _native.ptr(gr.packed),
+            gr.n_fields, gr.stride, gr.n_gates, float("nan"), _native.ptr(out), window, 0, _native.stream_ptr()),
+            "rg_csr_compact_apply_f32")
+
+    for cap in (c.window_cap, 512, 0):
+        got = torch.full_like(want, -7.0)
+        compact_apply(g_c, got, cap)
         assert bool(torch.equal(got.view(torch.int32), want.view(torch.int32))), f"window_cap={cap}"
     # and through the gridder's own apply()
     got = torch.empty_like(want)
     g_c.apply(got, fill_value=-9999.0)
     g_s.apply(want, fill_value=-9999.0)
     assert bool(torch.equal(got.view(torch.int32), want.view(torch.int32)))
+    # config 3: DBZH + ZDR + RHOHV with the RHOHV >= 0.8 mask, one fused pass through the compact copy
+    names = ["DBZH", "ZDR", "RHOHV"]
+    qc = rg.device_gate_mask(c2["fields"]["RHOHV"], "below", 0.8)
+    m_c = CsrGridder(geom, f.numel(), 3, device=dev, compact=True)
+    m_s = CsrGridder(geom, f.numel(), 3, device=dev)
+    assert m_c.compact is None and m_s.compact is None      # policy: 3 fused fields run the standard kernel (faster) ...
+    m_c.compact, m_c.window = c, c.window_for(3)            # ... but the compact kernel must give the same bits
+    two = CsrGridder(geom, f.numel(), 2, device=dev, compact=True)
+    assert two.compact is c                                 # 1-2 fields do go through the copy
+    for gr in (m_c, m_s):
+        gr.pack([c2["fields"][n] for n in names], [c2["masks"][n] for n in names], qc)
+    want3 = torch.empty((3, m_s.n_vox), dtype=torch.float32, device=dev)
+    got3 = torch.full_like(want3, -7.0)
+    m_s.apply(want3)
+    m_c.apply(got3)
+    assert bool(torch.equal(got3.view(torch.int32), want3.view(torch.int32)))
+    got3.fill_(-7.0)
+    compact_apply(m_c, got3, 256)
+    assert bool(torch.equal(got3.view(torch.int32), want3.view(torch.int32)))
 
 
-def test_c2_single_field_passes_switch_to_the_compact_copy(c2):
-    """gridding._use_compact: the first single-field pass of a geometry runs the standard kernel, the second builds the
-    compact copy and uses it from then on; multi-field passes never do.  Same bits every time."""
+def test_c2_passes_switch_to_the_compact_copy(c2):
+    """gridding._use_compact: the first pass of a geometry runs the standard kernel, the second builds the compact copy
+    and every later pass -- single- or multi-field -- uses it.  Same bits every time."""
     rg, torch, dev = c2["rg"], c2["torch"], c2["dev"]
     from radar_processor_amd.grid_geometry import GridGeometry
     geom = GridGeometry.from_device(c2["geom"].grid_shape, c2["geom"].grid_limits, c2["geom"].device_csr(dev), 17000.0)
     f, m = c2["fields"]["ZDR"], c2["masks"]["ZDR"]
     first = rg.grid_fields_device(geom, [f], [m]).clone()
     assert getattr(geom, "_compact", None) is None
-    rg.grid_fields_device(geom, [f, c2["fields"]["DBZH"]], [m, None])
-    assert getattr(geom, "_compact", None) is None
-    second = rg.grid_fields_device(geom, [f], [m]).clone()
+    two_a = rg.grid_fields_device(geom, [f, c2["fields"]["DBZH"]], [m, None]).clone()
     assert geom._compact is not None and geom._compact[1] is not None
-    third = rg.grid_fields_device(geom, [f], [m])
+    second = rg.grid_fields_device(geom, [f], [m]).clone()
+    two_b = rg.grid_fields_device(c2["geom"], [f, c2["fields"]["DBZH"]], [m, None])     # standard kernel (first use)
     assert torch.equal(first.view(torch.int32), second.view(torch.int32))
+    assert torch.equal(two_a.view(torch.int32), two_b.view(torch.int32))
+    assert len(geom._gridders) >= 2                                 # gridders (and staging buffers) are reused
+    third = rg.grid_fields_device(geom, [f], [m])
     assert torch.equal(first.view(torch.int32), third.view(torch.int32))
 
 
@@ -262,8 +292,9 @@ def test_c2_compact_only_layout(c2, tmp_path):
     want = rg.grid_fields_device(c2["geom"], [f], [m])
     got = rg.grid_fields_device(geom, [f], [m])
     assert torch.equal(got.view(torch.int32), want.view(torch.int32))
-    with pytest.raises(rg.NativeError):
-        rg.grid_fields_device(geom, [f, f], [m, m])
+    want2 = rg.grid_fields_device(c2["geom"], [f, c2["fields"]["ZDR"]], [m, None])
+    got2 = rg.grid_fields_device(geom, [f, c2["fields"]["ZDR"]], [m, None])      # multi-field works on the compact copy too
+    assert torch.equal(got2.view(torch.int32), want2.view(torch.int32))
     auto = rg.compute_grid_geometry(vol.gate_x, vol.gate_y, vol.gate_z, cfg["grid_shape"], cfg["grid_limits"],
                                     str(tmp_path), layout="auto")
     assert auto.device_csr(dev).gate_indices is not None

@@ -445,7 +445,8 @@ def test_fused_roi_grid_matches_reference(rg, name):
 # batch driver: fused field-volumes per CSR pass
 # ------------------------------------------------------------------------------------------------
 def test_volume_batch_fuses_passes(rg):
-    """5 volumes x 3 fields through VolumeBatch (2 volumes per fused pass) == per-volume apply_geometry_multi;
+    """5 volumes x 3 fields through VolumeBatch (one volume = 3 field-volumes per fused CSR pass; with 2 fields it
+    fuses 2 volumes) == per-volume apply_geometry_multi;
     products reducer keeps only 2-D planes; sharding by (rank, world) picks b mod world."""
     from radar_processor_amd import batch, synthetic
     name = "g3_c2_r060_barnes2"
@@ -455,7 +456,8 @@ def test_volume_batch_fuses_passes(rg):
     vols = [synthetic.make_volume(12, 360, 1000, seed=s, fields=names) for s in (0, 21, 22, 23, 24)]
     payload = [{n: (np.ma.getdata(v.fields[n]), np.ma.getmaskarray(v.fields[n])) for n in names} for v in vols]
     vb = batch.VolumeBatch(geom, names)
-    assert vb.volumes_per_pass == 2
+    assert vb.volumes_per_pass == 1 and batch.VolumeBatch(geom, names[:2]).volumes_per_pass == 2
+    assert batch.VolumeBatch(geom, names[:1]).volumes_per_pass == 4
     grids = vb.grid_shard(payload)
     assert sorted(grids) == [0, 1, 2, 3, 4]
     for b, v in enumerate(vols):

@@ -269,9 +269,14 @@ class TestNativeLibrary:
     def test_argument_validation_without_compute(self):
         """Entry points reject bad arguments before touching the device."""
         lib = rg.load_library(require_device=False)
-        assert lib.rg_csr_apply_f32(None, 0, None, None, 4, 0, None, 1, 1, 0, 0.0, None, None) == _native.RG_EINVAL
+        assert lib.rg_csr_apply_f32(None, 0, None, None, 4, 0, 0, None, 1, 1, 0, 0.0, None, None) == _native.RG_EINVAL
         assert b"null" in lib.rg_last_error()
-        assert lib.rg_csr_apply_f32(1 << 12, 0, None, None, 4, 0, None, 9, 8, 0, 0.0, 1 << 12, None) == _native.RG_EUNSUPPORTED
+        assert lib.rg_csr_apply_f32(1 << 12, 0, None, None, 4, 0, 0, None, 9, 8, 0, 0.0, 1 << 12, None) == _native.RG_EUNSUPPORTED
+        # n_vox must be a whole number of grid lines; the compact chunk count follows the documented formula
+        assert lib.rg_csr_apply_f32(1 << 12, 0, None, None, 10, 0, 4, None, 1, 1, 0, 0.0, 1 << 12, None) == _native.RG_EINVAL
+        assert lib.rg_csr_compact_chunks(40 * 2000 * 2000, 2000, 2000) == 40 * 500 * 32
+        assert lib.rg_csr_compact_chunks(3 * 17 * 29, 29, 17) == 3 * 5 * 1
+        assert lib.rg_csr_compact_chunks(1000, 0, 0) == 16 and lib.rg_csr_compact_chunks(10, 4, 0) == _native.RG_EINVAL
         assert lib.rg_column_reduce_f32(1 << 12, 4, 16, 0, 7, 0, 1 << 12, None, None) == _native.RG_EINVAL
         assert lib.rg_gate_mask_f32(1 << 12, 8, 99, 0.0, 0.0, 1 << 12, None) == _native.RG_EINVAL
         assert lib.rg_geom_bin_workspace_bytes(-1, 4, 4) == _native.RG_EINVAL
