@@ -270,6 +270,7 @@ int dispatch(int nf, int variant, const void* indptr, const int32_t* gidx, const
     switch (variant) {
       case 8: return RG_KD(1, 1, 512, kXcdSlab, 0);       // XCD placement
       case 16: return RG_KD(1, 1, 512, kXcdGroup, 0);
+      case 128: return RG_KD(1, 1, 128, kXcdNone, 0);
       case 256: case 18: return RG_KD(1, 1, 256, kXcdNone, 0);      // tile size
       case 23: return RG_KD(1, 1, 448, kXcdNone, 0);
       case 512: case 9: return RG_KD(1, 1, 512, kXcdNone, 0);

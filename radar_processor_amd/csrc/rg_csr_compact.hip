@@ -273,6 +273,7 @@ int launch(int nf, int tile, int window_cap, const void* indptr, const uint16_t*
   switch (nf) {
     case 1:
       switch (tile) {
+        case 128: return RG_K1C(1, 128);
         case 256: return RG_K1C(1, 256);
         case 512: return RG_K1C(1, 512);
         default: return RG_K1C(1, 384);
@@ -317,7 +318,9 @@ bool make_chunk_grid(int64_t n_rows, int64_t line_len, int64_t lines_per_plane, 
   cg->nyg = (unsigned)nyg;
   cg->seg_base = (unsigned)(line_len / nsx);
   cg->seg_extra = (unsigned)(line_len % nsx);
-  cg->rot_step = 1;   // measured on the bench grid: 0 -> 14.2 ms, 1 -> 9.8, 2 -> 9.7, 3 -> 9.8, 5 -> 9.6, 8 -> 10.5, 13 -> 9.8
+  // measured on the bench grid (32 columns), ms per launch: 0 -> 14.2 (every XCD keeps its columns), 8 -> 10.5,
+  // 1 -> 9.35, 2 -> 9.27, 3 -> 9.24, 5 -> 9.23, 7 -> 9.21, 9 -> 9.22, 11 -> 9.31, 17 -> 9.22
+  cg->rot_step = 5;
   return true;
 }
 
@@ -345,6 +348,8 @@ extern "C" int rg_csr_compact_apply_f32(const void* indptr, int32_t indptr_is_i6
              "rg_csr_compact_apply_f32: pairs present but local_idx/weights/dict/packed/n_gates missing");
   RG_REQUIRE(n_gates <= 0x7FFFFFFFL, RG_EUNSUPPORTED, "rg_csr_compact_apply_f32: n_gates exceeds int32 gate indices");
   RG_REQUIRE(n_vox <= 0x3FFFFFFFFFL, RG_EUNSUPPORTED, "rg_csr_compact_apply_f32: n_vox too large for one launch");
+  const int32_t rot_override = tile / 1000;   // diagnostic: tile = 1000 * rotation + tile selects the block rotation
+  tile %= 1000;
   RG_REQUIRE(tile == 0 || tile == 128 || tile == 256 || tile == 384 || tile == 512, RG_EINVAL,
              "rg_csr_compact_apply_f32: tile must be 0 (default), 128, 256, 384 or 512");
   RG_REQUIRE(window_cap >= 0 && window_cap <= RG_COMPACT_MAX_WINDOW, RG_EINVAL,
@@ -356,6 +361,7 @@ extern "C" int rg_csr_compact_apply_f32(const void* indptr, int32_t indptr_is_i6
              "rg_csr_compact_apply_f32: n_vox=%ld is not planes x lines_per_plane=%ld x line_len=%ld", (long)n_vox,
              (long)lines_per_plane, (long)line_len);
   RG_REQUIRE(chunk_count(cg) <= 0x7FFFFFFFL, RG_EUNSUPPORTED, "rg_csr_compact_apply_f32: too many chunks for one launch");
+  if (rot_override > 0) cg.rot_step = (unsigned)rot_override;
   hipStream_t s = (hipStream_t)stream;
   if (indptr_is_i64)
     return launch<int64_t>(n_fields, tile, window_cap, indptr, local_idx, weights, dict_ptr, dict, cg, n_vox, packed,

@@ -413,6 +413,31 @@ def test_metric_compact_equals_reference_format_bit_for_bit(metric):
         assert torch.equal(compact.decode(csr, r0, r1), csr.gate_indices[p0:p1])
 
 
+def test_metric_compact_only_layout_with_int64_offsets(metric, tmp_path):
+    """compute_grid_geometry(layout="compact") on the metric workload: the builder fills one slab of grid levels at a
+    time into a scratch index buffer addressed by ABSOLUTE pair offsets (pointer shifts of up to 8.3e9 * 4 bytes), so
+    this is the 64-bit path of the slab builder.  Row pointers and weights equal the standard build bit for bit, the
+    decoded indices equal its gate_indices beyond offset 2^31, and gridding gives the same bits."""
+    rg, torch, dev, vol, cfg = metric["rg"], metric["torch"], metric["dev"], metric["vol"], metric["cfg"]
+    std = metric["geom"].device_csr(dev)
+    k1, _ = _metric_grids(metric)
+    geom = rg.compute_grid_geometry(vol.gate_x, vol.gate_y, vol.gate_z, cfg["grid_shape"], cfg["grid_limits"],
+                                    str(tmp_path), layout="compact")
+    csr = geom.device_csr(dev)
+    assert csr.gate_indices is None and csr.is_i64 and csr.n_pairs == std.n_pairs and csr.max_gate == std.max_gate
+    assert torch.equal(csr.indptr, std.indptr)
+    assert torch.equal(csr.weights.view(torch.int32), std.weights.view(torch.int32))
+    compact = geom.device_compact(dev)
+    nz, ny, nx = cfg["grid_shape"]
+    for r0, r1 in (((21 * ny + 7) * nx + 3, (21 * ny + 12) * nx + 1999), ((39 * ny + 1990) * nx, csr.n_vox), (0, 3 * nx)):
+        p0, p1 = int(std.indptr[r0]), int(std.indptr[r1])
+        assert torch.equal(compact.decode(csr, r0, r1), std.gate_indices[p0:p1])
+    got = rg.grid_fields_device(geom, [metric["f"]], [metric["m"]])
+    assert torch.equal(got.view(-1).view(torch.int32), k1.view(-1).view(torch.int32))
+    del got, geom, compact, csr
+    torch.cuda.empty_cache()
+
+
 def test_metric_oracle_rows_beyond_2_31(metric):
     """oracle.csr_apply (the restatement of interpolate.py:69-104) on whole y-rows of the full-size CSR whose pair
     offsets lie beyond 2^31 -- including the first row past 2^31, the last row of the grid (last chunk) -- and the

@@ -62,7 +62,7 @@ def main():
             table_path = os.path.join(dst, "pmc_traffic.json")
             table = json.load(open(table_path)) if os.path.exists(table_path) else {}
             table[key] = {
-                "source": f"profiles/{tag}_pmc.csv",
+                "source": f"profiles/{tag}_pmc.csv", "tag": tag,
                 "kernel": info["roofline"]["kernel"],
                 "FETCH_SIZE_KiB": f_kib, "WRITE_SIZE_KiB": w_kib,
                 "correction": "read = 2 x FETCH_SIZE x 1024 (gfx950 tallies 128-B requests as 64 B), write = WRITE_SIZE x 1024",
