@@ -71,7 +71,8 @@ def parse_args(argv=None):
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal: every rank uses cuda:0 (needs --dist-backend gloo; RCCL refuses a shared GPU)")
     ap.add_argument("--cpu-sample-pairs", type=float, default=1.5e9, help="upper bound on CSR pairs in the CPU sample")
-    ap.add_argument("--cpu-workers", type=int, default=0, help="processes of the all-core CPU leg (0 = usable cores)")
+    ap.add_argument("--cpu-workers", type=int, default=0,
+                    help="processes of the all-core CPU leg (0 = min(usable cores, 16): the CPU share of a 1-GPU box)")
     return ap.parse_args(argv)
 
 
@@ -236,7 +237,7 @@ def cpu_baseline(pool, n_workers, geom, vol, field_name, n_vox_total, max_pairs)
         result["all_cores"] = {
             "value": round(n_vox_total / (total_pairs / rate) / 1e6, 4), "unit": "Mvoxel/s", "cores": len(jobs),
             "mpairs_per_s": round(rate / 1e6, 2), "seconds": round(best, 2),
-            "how": "one process per usable core (multiprocessing spawn), NumPy single-threaded, each gridding its own "
+            "how": "one process per core of the box's CPU share (multiprocessing spawn), NumPy single-threaded, each gridding its own "
                    "block of whole rows of the sample (equal pair counts), all at once; compute time of the slowest worker, best of 2",
         }
         result["value"], result["cores"] = result["all_cores"]["value"], len(jobs)
@@ -308,7 +309,9 @@ def run_rank(args):
     if want_cpu:
         import multiprocessing as mp
         _, _, usable = _cpu_identity()
-        n_workers = args.cpu_workers or usable
+        # a 1-GPU lease of this pool comes with a CPU share of 16 cores, whatever the affinity mask says (256 on the
+        # EPYC 9575F hosts): one worker per core of that share unless --cpu-workers says otherwise
+        n_workers = args.cpu_workers or min(usable, 16)
         if n_workers > 1:
             pool = mp.get_context("spawn").Pool(n_workers)
 
