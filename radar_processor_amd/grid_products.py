@@ -110,6 +110,36 @@ def _finish(t, as_numpy: bool):
     return t.cpu().numpy() if as_numpy else t
 
 
+def cappi_plan(z_limits, nz: int, altitude: float, interpolation: str = "linear"):
+    """The scalar decisions of a CAPPI, taken once on the host (``radar_grid/products.py:361-404``), as a tuple:
+
+    * ``("outside",)`` -- ``altitude`` is not within ``[z_min, z_max]``: all-NaN plane;
+    * ``("level", k)`` -- the plane IS level ``k`` (nearest-level mode, an exact level hit within ``rtol=1e-6``, or a
+      fractional position that falls off either end);
+    * ``("blend", k, w_k, w_k1)`` -- float32 blend of levels ``k`` and ``k + 1``.
+
+    Level altitudes are the float32 ``linspace`` of the limits; the fractional position uses the float64 step.
+    """
+    lo, hi = z_limits
+    if not lo <= altitude <= hi:
+        return ("outside",)
+    levels = np.linspace(lo, hi, nz, dtype="float32")
+    if interpolation == "nearest":
+        return ("level", int(np.abs(levels - altitude).argmin()))
+    if interpolation != "linear":
+        raise ValueError(f"Unknown interpolation method: {interpolation}")
+    exact = np.flatnonzero(np.isclose(levels, altitude, rtol=1e-6))
+    if exact.size:
+        return ("level", int(exact[0]))
+    spacing = (hi - lo) / (nz - 1) if nz > 1 else 1.0
+    position = (altitude - lo) / spacing
+    k = int(np.floor(position))
+    if k < 0 or k + 1 >= nz:
+        return ("level", min(max(k, 0), nz - 1))
+    upper = position - k
+    return ("blend", k, 1.0 - upper, upper)
+
+
 def constant_altitude_ppi(grid, geometry: GridGeometry, altitude: float, interpolation: str = "linear"):
     """CAPPI at ``altitude`` metres (``radar_grid/products.py:317-415``).
 
@@ -117,43 +147,24 @@ def constant_altitude_ppi(grid, geometry: GridGeometry, altitude: float, interpo
     level of ``grid`` (a view, like the reference); otherwise the float32 lerp of the two bracketing levels.
     """
     nz, ny, nx = geometry.grid_shape
-    z_min, z_max = geometry.grid_limits[0]
-    z_coords = np.linspace(z_min, z_max, nz, dtype="float32")
-
-    if altitude < z_min or altitude > z_max:
+    plan = cappi_plan(geometry.grid_limits[0], nz, altitude, interpolation)
+    if plan[0] == "outside":
+        z_min, z_max = geometry.grid_limits[0]
         logger.warning(f"Altitude {altitude}m is outside grid range [{z_min}, {z_max}]m")
         if _is_tensor(grid):
             return grid.new_full((ny, nx), float("nan"))
         return np.full((ny, nx), np.nan, dtype="float32")
-
-    if interpolation == "nearest":
-        return grid[int(np.argmin(np.abs(z_coords - altitude))), :, :]
-    if interpolation != "linear":
-        raise ValueError(f"Unknown interpolation method: {interpolation}")
-
-    z_matches = np.isclose(z_coords, altitude, rtol=1e-6)
-    if np.any(z_matches):
-        return grid[int(np.where(z_matches)[0][0]), :, :]
-
-    z_step = (z_max - z_min) / (nz - 1) if nz > 1 else 1.0
-    z_frac = (altitude - z_min) / z_step
-    z_low = int(np.floor(z_frac))
-    if z_low < 0:
-        return grid[0, :, :]
-    if z_low + 1 >= nz:
-        return grid[nz - 1, :, :]
-    weight_high = z_frac - z_low
-    weight_low = 1.0 - weight_high
-
+    if plan[0] == "level":
+        return grid[plan[1], :, :]
+    _, k, w_k, w_k1 = plan
     torch = _native.torch_mod()
     lib = _native.load_library()
     g, as_numpy = _to_device_grid(grid)
     out = torch.empty((ny, nx), dtype=torch.float32, device=g.device)
     with torch.cuda.device(g.device):
         # weak Python-float weights act as float32 under NumPy >= 2 (SURVEY.md F8)
-        _native.check(lib.rg_cappi_lerp_f32(_native.ptr(g), ny * nx, z_low, float(np.float32(weight_low)),
-                                            float(np.float32(weight_high)), _native.ptr(out), _native.stream_ptr()),
-                      "rg_cappi_lerp_f32")
+        _native.check(lib.rg_cappi_lerp_f32(_native.ptr(g), ny * nx, k, float(np.float32(w_k)), float(np.float32(w_k1)),
+                                            _native.ptr(out), _native.stream_ptr()), "rg_cappi_lerp_f32")
     return _finish(out, as_numpy)
 
 

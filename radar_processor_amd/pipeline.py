@@ -52,23 +52,11 @@ class VolumePipeline:
 
     def _plan_cappi(self, altitude: float):
         """Scalar control flow of constant_altitude_ppi (radar_grid/products.py:361-404), resolved once."""
-        nz = self.shape[0]
-        z_min, z_max = self.geometry.grid_limits[0]
-        zc = np.linspace(z_min, z_max, nz, dtype="float32")
-        if altitude < z_min or altitude > z_max:
-            return ("nan",)
-        hit = np.isclose(zc, altitude, rtol=1e-6)
-        if np.any(hit):
-            return ("level", int(np.where(hit)[0][0]))
-        z_step = (z_max - z_min) / (nz - 1) if nz > 1 else 1.0
-        z_frac = (altitude - z_min) / z_step
-        k = int(np.floor(z_frac))
-        if k < 0:
-            return ("level", 0)
-        if k + 1 >= nz:
-            return ("level", nz - 1)
-        w_hi = z_frac - k
-        return ("lerp", k, float(np.float32(1.0 - w_hi)), float(np.float32(w_hi)))
+        from .grid_products import cappi_plan
+        plan = cappi_plan(self.geometry.grid_limits[0], self.shape[0], altitude)
+        if plan[0] == "blend":
+            return ("lerp", plan[1], float(np.float32(plan[2])), float(np.float32(plan[3])))
+        return ("nan",) if plan[0] == "outside" else plan
 
     def _enqueue(self) -> None:
         lib, ptr, stream = self.lib, _native.ptr, _native.stream_ptr()
