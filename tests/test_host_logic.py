@@ -337,3 +337,80 @@ class TestBenchLauncher:
             pytest.skip("box has 8 GPUs")
         res = self._run(["--gpus", "8"], {})
         assert res.returncode == 2 and b"refusing to label a smaller run" in res.stderr and not res.stdout.strip()
+
+
+class TestCompactLayoutHostLogic:
+    """Chunk / segment arithmetic of the compact CSR copy (grid_geometry.CompactCSR) -- the host side must cut lines and
+    number chunks exactly as csrc/rg_csr_compact.hip does (checked against rg_csr_compact_chunks, no GPU needed)."""
+
+    def test_segments_are_balanced_and_cover_the_line(self):
+        from radar_processor_amd.grid_geometry import CompactCSR
+        for nx in (1, 5, 63, 64, 65, 128, 255, 300, 1000, 2000, 4097):
+            st = CompactCSR.segment_starts(nx)
+            widths = np.diff(st)
+            assert st[0] == 0 and st[-1] == nx and len(widths) == (nx + 63) // 64
+            assert widths.max() <= 64 and widths.max() - widths.min() <= 1 and (np.diff(widths) <= 0).all()
+
+    def test_chunk_numbering_matches_the_library(self):
+        import torch
+        from radar_processor_amd.grid_geometry import CompactCSR
+        lib = rg.load_library(require_device=False)
+        for shape in ((1, 1, 1), (3, 17, 29), (2, 5, 300), (40, 2000, 2000), (20, 1000, 1000), (1, 4, 64)):
+            nz, ny, nx = shape
+            nsx, nyg, n_chunks = CompactCSR.layout(shape)
+            assert n_chunks == lib.rg_csr_compact_chunks(nz * ny * nx, nx, ny)
+            assert nsx == (nx + 63) // 64 and nyg == (ny + _native.RG_COMPACT_LINES - 1) // _native.RG_COMPACT_LINES
+        shape = (2, 6, 150)                          # 3 segments of 50 rows, 2 line groups (4 + 2 lines), 2 planes
+        rows = torch.arange(2 * 6 * 150)
+        chunk = CompactCSR.chunk_of_rows(rows, shape).view(2, 6, 150)
+        assert chunk.max().item() + 1 == CompactCSR.layout(shape)[2] == 2 * 2 * 3
+        for z in range(2):
+            for y in range(6):
+                for sx in range(3):
+                    want = (z * 2 + y // 4) * 3 + sx
+                    assert bool((chunk[z, y, sx * 50:(sx + 1) * 50] == want).all())
+
+    def test_window_choice(self):
+        import torch
+        from radar_processor_amd.grid_geometry import CompactCSR
+        c = CompactCSR(torch.zeros(0, dtype=torch.int16), torch.zeros(5, dtype=torch.int64), torch.zeros(0, dtype=torch.int32),
+                       900, 768, (1, 16, 64), chunk_pairs=torch.tensor([100, 100, 100, 700]),
+                       chunk_counts=torch.tensor([10, 300, 800, 900]))
+        assert c.window_for(1) == 768 and c.window_for(2) == 768 and c.window_for(3) == 768 and c.window_for(8) == 768
+        c.window_cap = 4096
+        assert c.window_for(1) == 4096 and c.window_for(3) == 2048 and c.window_for(8) == 1024     # 32 KiB of LDS
+        assert c.fallback_fraction(1000) == 0.0 and abs(c.fallback_fraction(850) - 0.7) < 1e-9
+        assert abs(c.fallback_fraction(256) - 0.9) < 1e-9
+
+
+class TestGeometryAssignment:
+    """Plain attribute assignment works as on the reference dataclass: nothing is lost, caches are dropped."""
+
+    def test_setters_keep_the_other_arrays(self):
+        ip = np.array([0, 1, 3], dtype=np.int32)
+        g = rg.GridGeometry((1, 1, 2), ((0, 0), (0, 0), (0, 1)), ip, np.array([0, 1, 2], dtype=np.int32),
+                            np.ones(3, dtype=np.float32), toa=10.0)
+        g._gridders = {"stale": object()}
+        g._compact = ("stale", None)
+        g.weights = np.array([0.5, 0.25, 0.25], dtype=np.float32)
+        assert np.array_equal(g.indptr, ip) and np.array_equal(g.gate_indices, [0, 1, 2])
+        assert np.array_equal(g.weights, [0.5, 0.25, 0.25])
+        assert "_gridders" not in g.__dict__ and "_compact" not in g.__dict__ and not g.is_device_resident
+        g.gate_indices = np.array([2, 1, 0], dtype=np.int32)
+        g.indptr = np.array([0, 2, 3], dtype=np.int32)
+        assert g.n_pairs() == 3 and np.array_equal(g.indptr, [0, 2, 3]) and np.array_equal(g.weights, [0.5, 0.25, 0.25])
+        g.invalidate_device()                     # a no-op without a device copy
+        assert np.array_equal(g.gate_indices, [2, 1, 0])
+
+    def test_cappi_plan(self):
+        from radar_processor_amd.grid_products import cappi_plan
+        assert cappi_plan((0.0, 15000.0), 20, 99000.0) == ("outside",)
+        assert cappi_plan((0.0, 19000.0), 20, 4000.0) == ("level", 4)                      # exact level: a view
+        kind, k, w0, w1 = cappi_plan((0.0, 15000.0), 20, 4000.0)
+        assert (kind, k) == ("blend", 5) and abs(w1 - (4000.0 / (15000.0 / 19) - 5)) < 1e-12 and abs(w0 + w1 - 1) < 1e-12
+        assert cappi_plan((0.0, 15000.0), 20, 4000.0, "nearest") == ("level", 5)
+        for alt in (0.0, 1234.5, 7777.0, 15000.0):
+            mine, ref = cappi_plan((0.0, 15000.0), 20, alt), oracle.cappi_plan((0.0, 15000.0), 20, alt)
+            assert mine[1:] == ref[1:]
+        with pytest.raises(ValueError, match="Unknown interpolation method"):
+            cappi_plan((0.0, 1.0), 2, 0.5, "cubic")
