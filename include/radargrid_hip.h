@@ -317,7 +317,9 @@ int rg_grid_filter(const void* src, int32_t data_is_f64, int64_t n, int32_t flag
  * rg_csr_apply_f32 for the same field count; other values change the order of the float32 adds).
  * line_len <= 0 means one line of n_vox rows, lines_per_plane <= 0 one plane.
  * ------------------------------------------------------------------------------------------------- */
+#ifndef RG_COMPACT_LINES
 #define RG_COMPACT_LINES 4
+#endif
 #define RG_COMPACT_MAX_WINDOW 8192
 int rg_csr_compact_apply_f32(const void* indptr, int32_t indptr_is_i64, const uint16_t* local_idx, const float* weights,
                              const int64_t* dict_ptr, const int32_t* dict, int64_t n_vox, int64_t n_pairs,

@@ -25,7 +25,7 @@ RG_MAX_PLANE_TESTS = 12
 RG_TEST_LO, RG_TEST_HI, RG_TEST_LO_INCLUSIVE, RG_TEST_NONFINITE = 1, 2, 4, 8
 RG_MINMAX_WORKSPACE_BYTES = 32768
 RG_MAX_LUT = 4093
-RG_COMPACT_LINES = 4          # grid lines (= wavefronts) per chunk of the compact CSR copy
+RG_COMPACT_LINES = 4          # grid lines (= wavefronts) per chunk of the compact CSR copy (header: RG_COMPACT_LINES)
 RG_COMPACT_MAX_WINDOW = 8192
 
 

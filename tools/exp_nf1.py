@@ -16,8 +16,9 @@ f = torch.from_numpy(np.ascontiguousarray(np.ma.getdata(vol.fields["DBZH"]))).to
 m = torch.from_numpy(np.ma.getmaskarray(vol.fields["DBZH"]).astype(np.uint8)).to(dev)
 g = CsrGridder(geom, f.numel(), 1, device=dev, compact=True)
 g.pack([f], [m])
+print('window', g.window, 'dict B/pair', 4 * g.compact.n_dict / g.csr.n_pairs, 'max_dict', g.compact.max_dict)
 out = torch.empty((1, g.n_vox), dtype=torch.float32, device=dev)
-variants = [(t, r) for t in (128, 256, 384, 512) for r in (1, 5)] + [(384, r) for r in (2, 3, 7, 9, 11, 17)]
+variants = [(384, r) for r in (1, 3, 5, 7)] + [(256, 5)]
 times = {v: [] for v in variants}
 for rnd in range(6):
     for t, r in variants:
