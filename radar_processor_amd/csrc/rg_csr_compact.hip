@@ -104,8 +104,9 @@ __global__ __launch_bounds__(64 * kH) void csr_compact_kernel(
   // Workgroups are dealt to the 8 XCDs round-robin by blockIdx.  With nsx segments per line a multiple of 8, chunk
   // column sx would always land on XCD sx % 8; rotating the columns by one per line group makes every XCD see every
   // column (speed only: the chunk a workgroup takes is still a bijection of blockIdx).
-  const unsigned grp = blockIdx.x / cg.nsx;
-  const unsigned col = blockIdx.x - grp * cg.nsx;
+  const unsigned bid = blockIdx.x;
+  const unsigned grp = bid / cg.nsx;
+  const unsigned col = bid - grp * cg.nsx;
   const unsigned rot = (col + (grp * cg.rot_step) % cg.nsx);
   const unsigned chunk = grp * cg.nsx + (rot >= cg.nsx ? rot - cg.nsx : rot);
   const long d0 = dict_ptr[chunk];
@@ -201,7 +202,8 @@ __global__ __launch_bounds__(64 * kH) void csr_compact_kernel(
           }
         } else {
           const unsigned g0 = (unsigned)cdict[pos];
-          rg::load_packed<STRIDE>(packed, g0 < last_gate ? g0 : last_gate, val[it]);
+          const unsigned gc = g0 < last_gate ? g0 : last_gate;
+          rg::load_packed<STRIDE>(packed, gc, val[it]);
         }
       }
       // ---- products of tile t -> LDS (layout and arithmetic: rg_row_phase.hpp) ----------------------------------
@@ -287,13 +289,17 @@ int launch(int nf, int tile, int window_cap, const void* indptr, const uint16_t*
     case 3:
       switch (tile) {
         case 128: return RG_K1C(3, 128);
+        case 192: return RG_K1C(3, 192);
+        case 256: return RG_K1C(3, 256);
         case 384: return RG_K1C(3, 384);
-        default: return RG_K1C(3, 256);
+        default: return RG_K1C(3, 320);
       }
     case 4:
       switch (tile) {
         case 128: return RG_K1C(4, 128);
-        default: return RG_K1C(4, 256);
+        case 256: return RG_K1C(4, 256);
+        case 384: return RG_K1C(4, 384);
+        default: return RG_K1C(4, 320);
       }
     case 5: return RG_K1C(5, 128);
     case 6: return RG_K1C(6, 128);
@@ -350,8 +356,8 @@ extern "C" int rg_csr_compact_apply_f32(const void* indptr, int32_t indptr_is_i6
   RG_REQUIRE(n_vox <= 0x3FFFFFFFFFL, RG_EUNSUPPORTED, "rg_csr_compact_apply_f32: n_vox too large for one launch");
   const int32_t rot_override = tile / 1000;   // diagnostic: tile = 1000 * rotation + tile selects the block rotation
   tile %= 1000;
-  RG_REQUIRE(tile == 0 || tile == 128 || tile == 256 || tile == 384 || tile == 512, RG_EINVAL,
-             "rg_csr_compact_apply_f32: tile must be 0 (default), 128, 256, 384 or 512");
+  RG_REQUIRE(tile == 0 || tile == 128 || tile == 192 || tile == 256 || tile == 320 || tile == 384 || tile == 512, RG_EINVAL,
+             "rg_csr_compact_apply_f32: tile must be 0 (default), 128, 192, 256, 320, 384 or 512");
   RG_REQUIRE(window_cap >= 0 && window_cap <= RG_COMPACT_MAX_WINDOW, RG_EINVAL,
              "rg_csr_compact_apply_f32: window_cap %d outside 0..%d", window_cap, RG_COMPACT_MAX_WINDOW);
   RG_REQUIRE(rg::aligned16(packed), RG_EALIGN, "rg_csr_compact_apply_f32: packed must be 16-byte aligned");

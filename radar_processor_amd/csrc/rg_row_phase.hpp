@@ -7,10 +7,12 @@
 // kernels agree bit for bit: same lane split, same order of float32 additions.
 //
 // LDS image of a tile (per wavefront):
-//   one field   f32x2 tile[TILE]                       (w*v, w) per pair, 0 for an excluded gate
-//   F > 1       float  P[TILE][STRIDE], W[TILE][STRIDE] w*v_f and the masked weight per field slot, 0 where excluded or
-//                                                      padding -- two arrays, so a pair's entry is one 8 / 16 / 32-byte
-//                                                      vector access at a lane stride of the same size (conflict-free)
+//   one field   f32x2 tile[TILE]                   (w*v, w) per pair, 0 for an excluded gate
+//   F > 1       float V[TILE][STRIDE], W[TILE]     the pair's raw field slots (sentinel = excluded) and its weight; for 3
+//                                                  fields the weight rides in the padding slot: one 16-byte entry.  A
+//                                                  pair's entry is one 8 / 16 / 32-byte vector access at a lane stride
+//                                                  of the same size (conflict-free); the row-phase lanes do the mask
+//                                                  test and the product
 // Lane split: L = 2^lg lanes per row, the largest power of two <= 64 / (rows touching the tile); lane k of a row sums
 // pairs k, k+L, k+2L, ... of the row's part of the tile with two independent accumulators per value (elements k, k+2L,
 // ... and k+L, k+3L, ...), ALL F fields at once ("whole-entry" lanes: one vector read feeds 2F additions, where one
@@ -63,9 +65,15 @@ __device__ __forceinline__ void butterfly(float (&v)[N], int nsub) {
   }
 }
 
-constexpr int tile_floats(int nf, int stride) { return nf == 1 ? 2 : 2 * stride; }   // LDS floats per pair
+// LDS floats per pair: (w*v, w) for one field; the raw field slots + the weight for several (the weight rides in the
+// padding slot of a 3-field entry, otherwise in its own array behind the values)
+constexpr int tile_floats(int nf, int stride) { return nf == 1 ? 2 : nf == 3 ? 4 : stride + 1; }
 
 // ---- product side: one pair -> its LDS entry --------------------------------------------------------------------
+// One field: the masked products (w*v, w).  Several fields: the pair's RAW packed slots (EXCLUDED sentinel = masked)
+// and its weight -- 12 / 16 / 20 / 36 bytes instead of the 16 / 32 / 32 / 64 of F (w*v, w) pairs.  LDS stores are the
+// slow direction of this part (about 70 B/clk/CU against 256 for loads), so the mask test and the product are done by
+// the row-phase lanes, which are fully occupied anyway, and the tile carries the fewest bytes that define them.
 template <int NF, int STRIDE>
 __device__ __forceinline__ void store_products(float* __restrict__ tile, int tile_pairs, int e, float w,
                                                const float (&v)[STRIDE]) {
@@ -75,26 +83,17 @@ __device__ __forceinline__ void store_products(float* __restrict__ tile, int til
     p.x = ok ? w * v[0] : 0.0f;
     p.y = ok ? w : 0.0f;
     reinterpret_cast<f32x2*>(tile)[e] = p;
+  } else if constexpr (NF == 3) {
+    reinterpret_cast<f32x4*>(tile)[e] = (f32x4){v[0], v[1], v[2], w};
   } else {
-    float p[STRIDE], m[STRIDE];
-#pragma unroll
-    for (int f = 0; f < STRIDE; ++f) {   // padding slots hold the sentinel -> (0, 0)
-      const bool ok = f < NF && f32_bits(v[f]) != RG_EXCLUDED_BITS;
-      p[f] = ok ? w * v[f] : 0.0f;
-      m[f] = ok ? w : 0.0f;
-    }
-    float* __restrict__ pp = tile + (size_t)e * STRIDE;
-    float* __restrict__ ww = tile + (size_t)tile_pairs * STRIDE + (size_t)e * STRIDE;
+    float* __restrict__ vv = tile + (size_t)e * STRIDE;
     if constexpr (STRIDE == 2) {
-      *reinterpret_cast<f32x2*>(pp) = (f32x2){p[0], p[1]};
-      *reinterpret_cast<f32x2*>(ww) = (f32x2){m[0], m[1]};
+      *reinterpret_cast<f32x2*>(vv) = (f32x2){v[0], v[1]};
     } else {
 #pragma unroll
-      for (int q = 0; q < STRIDE; q += 4) {
-        *reinterpret_cast<f32x4*>(pp + q) = (f32x4){p[q], p[q + 1], p[q + 2], p[q + 3]};
-        *reinterpret_cast<f32x4*>(ww + q) = (f32x4){m[q], m[q + 1], m[q + 2], m[q + 3]};
-      }
+      for (int q = 0; q < STRIDE; q += 4) *reinterpret_cast<f32x4*>(vv + q) = (f32x4){v[q], v[q + 1], v[q + 2], v[q + 3]};
     }
+    tile[(size_t)tile_pairs * STRIDE + e] = w;
   }
 }
 
@@ -132,32 +131,35 @@ __device__ __forceinline__ void row_phase(const float* __restrict__ tile, f32x2*
       butterfly<2>(sv, nsub);
       if (live && sub == 0) rowacc[myrow] += (f32x2){sv[0], sv[1]};  // one owner per row: plain read-modify-write
     } else {
-      const float* __restrict__ pp = tile;
-      const float* __restrict__ ww = tile + (size_t)TILE * STRIDE;
       float p0[NF], w0[NF], p1[NF], w1[NF];
 #pragma unroll
       for (int f = 0; f < NF; ++f) p0[f] = w0[f] = p1[f] = w1[f] = 0.0f;
       auto add = [&](float (&ap)[NF], float (&aw)[NF], int j) {
-        float ep[STRIDE], ew[STRIDE];
-        if constexpr (STRIDE == 2) {
-          const f32x2 x = *reinterpret_cast<const f32x2*>(pp + (size_t)j * 2);
-          const f32x2 y = *reinterpret_cast<const f32x2*>(ww + (size_t)j * 2);
-          ep[0] = x.x; ep[1] = x.y; ew[0] = y.x; ew[1] = y.y;
+        float ev[STRIDE], w;
+        if constexpr (NF == 3) {
+          const f32x4 x = reinterpret_cast<const f32x4*>(tile)[j];
+          ev[0] = x.x; ev[1] = x.y; ev[2] = x.z; w = x.w;
         } else {
+          const float* __restrict__ vv = tile + (size_t)j * STRIDE;
+          if constexpr (STRIDE == 2) {
+            const f32x2 x = *reinterpret_cast<const f32x2*>(vv);
+            ev[0] = x.x; ev[1] = x.y;
+          } else {
 #pragma unroll
-          for (int q = 0; q < STRIDE; q += 4) {
-            if (q < NF) {   // whole vectors of padding slots are not even read
-              const f32x4 x = *reinterpret_cast<const f32x4*>(pp + (size_t)j * STRIDE + q);
-              const f32x4 y = *reinterpret_cast<const f32x4*>(ww + (size_t)j * STRIDE + q);
-              ep[q] = x.x; ep[q + 1] = x.y; ep[q + 2] = x.z; ep[q + 3] = x.w;
-              ew[q] = y.x; ew[q + 1] = y.y; ew[q + 2] = y.z; ew[q + 3] = y.w;
+            for (int q = 0; q < STRIDE; q += 4) {
+              if (q < NF) {   // whole vectors of padding slots are not even read
+                const f32x4 x = *reinterpret_cast<const f32x4*>(vv + q);
+                ev[q] = x.x; ev[q + 1] = x.y; ev[q + 2] = x.z; ev[q + 3] = x.w;
+              }
             }
           }
+          w = tile[(size_t)TILE * STRIDE + j];
         }
 #pragma unroll
-        for (int f = 0; f < NF; ++f) {
-          ap[f] += ep[f];
-          aw[f] += ew[f];
+        for (int f = 0; f < NF; ++f) {   // masked gate: contributes to neither sum (interpolate.py:78-79)
+          const bool ok = f32_bits(ev[f]) != RG_EXCLUDED_BITS;
+          ap[f] += ok ? w * ev[f] : 0.0f;
+          aw[f] += ok ? w : 0.0f;
         }
       };
       int j = a + sub;

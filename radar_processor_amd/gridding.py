@@ -94,12 +94,17 @@ class CsrGridder:
             raise IndexError(f"index {self.csr.max_gate} is out of bounds for axis 0 with size {self.n_gates}")
         self.packed = torch.empty(max(self.n_gates, 1) * self.stride, dtype=torch.float32, device=self.dev)
         compact_only = self.csr.gate_indices is None
-        # Measured (config 2 / bench grid, ms per pass, standard vs compact kernel): 1 field 1.81 / 1.28 and 13.1 / 9.5,
-        # 2 fields 1.80 / 1.85 and 14.9 / 13.0, 3 fields 2.60 / 3.45 and 18.8 / 20.7, 4 fields 2.89 / 3.71 and 20.7 /
-        # 22.5: from 3 fields on the 16-byte window entries and the 32-byte tile entries leave the compact kernel two or
-        # three workgroups per CU, and the standard kernel -- no window -- wins.  A compact-only geometry has no choice.
-        want = (compact and self.n_fields <= _COMPACT_MAX_FIELDS) or compact_only
+        # Measured (config 2 / bench grid, ms per pass, standard vs compact kernel): 1 field 1.81 / 1.28 and 13.1 / 9.3,
+        # 2 fields 2.1 / 1.76 and 15.2 / 13.3, 3 fields 2.37 / 2.68 and 16.9 / 15.1, 4 fields 2.86 / 3.4 and 19.8 / 19.3,
+        # 8 fields 7.3 / 9.6 and 49.8 / 65.  What decides is the LDS window the compact kernel needs next to its tiles:
+        # up to about 16 KiB (bench grid: 768 entries x 16 bytes; config 2: 1792 x 8) it keeps enough workgroups per
+        # CU to win, beyond that (config 2 with 16-byte entries: 28 KiB; any 8-field pass) the standard kernel -- no
+        # window -- does.  A compact-only geometry has no choice.
+        want = compact or compact_only
         self.compact = geometry.device_compact(self.dev) if (want and self.csr.n_pairs) else None
+        if (self.compact is not None and not compact_only
+                and self.compact.window_for(self.n_fields) * 4 * self.stride > _COMPACT_MAX_WINDOW_BYTES):
+            self.compact = None
         self.window = 0
         if self.compact is not None:
             self.window = self.compact.window_for(self.n_fields)
@@ -170,7 +175,7 @@ class CsrGridder:
 
 
 _COMPACT_MIN_PAIRS = 50_000_000     # below this a pass takes well under a millisecond either way
-_COMPACT_MAX_FIELDS = 2            # fused passes of more fields run the standard kernel (see CsrGridder.__init__)
+_COMPACT_MAX_WINDOW_BYTES = 16384  # LDS window beyond which the standard kernel is the faster one (CsrGridder.__init__)
 _COMPACT_MAX_FALLBACK = 0.02        # share of pairs allowed on the per-pair path before the standard kernel is preferred
 
 
