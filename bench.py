@@ -465,6 +465,27 @@ def run_rank(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else float("nan")
+
+    # ---- the grid that was just timed is checked, outside the timed region (rank 0) ------------------------------
+    # the compact kernel against the reference-format kernel on the same inputs: every voxel, bit for bit; and the
+    # filled / empty pattern against the row pointers.  (Full parity against the oracle: tests/test_gpu_fullsize.py.)
+    checked = None
+    if rank == 0 and not c5 and args.mode == "csr":
+        csr_now = gridder.csr
+        nonempty = (csr_now.indptr[1:] - csr_now.indptr[:-1]) > 0
+        filled = torch.isfinite(out[0])
+        assert bool((filled <= nonempty).all()), "a voxel without neighbours was filled"
+        checked = f"{int(filled.sum())} of {n_vox} voxels filled, none of them in an empty row"
+        if gridder.compact is not None and csr_now.gate_indices is not None:
+            ref_gridder = CsrGridder(geom, n_gates, fields_per_pass, device=dev, compact=False)
+            ref_gridder.pack(fields_d, masks_d, shared)
+            ref_out = torch.empty_like(out)
+            ref_gridder.apply(ref_out)
+            assert bool(torch.equal(ref_out.view(torch.int32), out.view(torch.int32))), \
+                "compact kernel and reference-format kernel disagree on the timed grid"
+            checked += "; rg_csr_compact_apply_f32 == rg_csr_apply_f32 bit for bit on all of them"
+            del ref_out, ref_gridder
+        del nonempty, filled
     launches_per_step = len(events) / max(args.steps, 1)
 
     if rank == 0:
@@ -494,6 +515,7 @@ def run_rank(args):
             "config": {"workload": workload, "key": workload_key, "gates": n_gates, "voxels": n_vox,
                        "pairs": n_pairs, "fields_per_pass": fields_per_pass, "volumes_total": total_vol,
                        "ranks_seen_by_process_group": dist.get_world_size() if world > 1 else 1,
+                       "checked": checked,
                        "step": "pack_fields + " + (("csr_compact_apply" if compact_on else "csr_apply") if args.mode == "csr"
                                                    else "roi_grid")
                                + " + colmax/argmax + cappi4000 per field-volume"},

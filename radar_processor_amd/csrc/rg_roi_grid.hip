@@ -92,13 +92,16 @@ __global__ __launch_bounds__(rg::kBlock) void roi_block_kernel(SearchArgs a, con
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   rg_gate4* ring = ring_all[wv];
   float* ringv = ringv_all[wv];
-  const long wpx = (a.nx + PX - 1) / PX, wpy = (a.ny + BY - 1) / BY;   // patches per level
-  const long wave = (long)blockIdx.x * (rg::kBlock / rg::kWave) + wv;
-  const long iz_l = wave / (wpx * wpy);
-  if (iz_l >= a.nz) return;                                      // wave-uniform
-  const long rem = wave - iz_l * (wpx * wpy);
+  // 32-bit on purpose: a 64-bit division costs this ISA a few hundred instructions, and every wavefront does three
+  // (the launcher guarantees that the patch count fits)
+  const unsigned wpx = (unsigned)((a.nx + PX - 1) / PX), wpy = (unsigned)((a.ny + BY - 1) / BY);   // patches per level
+  const unsigned wave = blockIdx.x * (unsigned)(rg::kBlock / rg::kWave) + (unsigned)wv;
+  const unsigned iz_l = wave / (wpx * wpy);
+  if (iz_l >= (unsigned)a.nz) return;                            // wave-uniform
+  const unsigned rem = wave - iz_l * (wpx * wpy);
   const int iz = (int)iz_l;
-  const int iy0 = (int)(rem / wpx) * BY, ix0 = (int)(rem % wpx) * PX;
+  const unsigned py = rem / wpx;
+  const int iy0 = (int)py * BY, ix0 = (int)(rem - py * wpx) * PX;
   const int nvy = a.ny - iy0 < BY ? a.ny - iy0 : BY;
   const double z = (double)a.zc[iz];                             // common to the whole wave
   const float zf = (float)z;                                     // grid coordinates ARE float32 values: exact
@@ -390,7 +393,7 @@ extern "C" int rg_roi_grid_f32(const rg_gate4* sorted_gates, const int32_t* cell
   RG_REQUIRE(stride == stride_for(n_fields), RG_EINVAL, "rg_roi_grid_f32: stride=%d, expected %d for %d fields", stride,
              stride_for(n_fields), n_fields);
   RG_REQUIRE(rg::aligned16(packed), RG_EALIGN, "rg_roi_grid_f32: packed must be 16-byte aligned");
-  RG_REQUIRE((long)nx * ny * nz > 0 && (long)((nx + 15) / 16) * ny * nz < 0x3FFFFFFFFL, RG_EUNSUPPORTED,
+  RG_REQUIRE((long)nx * ny * nz > 0 && (long)((nx + 31) / 32) * ((ny + 1) / 2) * nz < 0xFFFFFFF0L, RG_EUNSUPPORTED,
              "rg_roi_grid_f32: grid too large for one launch");
   const SearchArgs a = make_args(sorted_gates, cell_start, cells_host, xc, yc, zc, nz, ny, nx, min_radius, beam_factor);
   hipStream_t s = (hipStream_t)stream;
