@@ -291,7 +291,7 @@ def test_compact_csr_edge_shapes(rg, tmp_path, shape):
 
 
 def test_compact_csr_rich_chunks(rg):
-    """Chunks far richer than the radar geometries produce: ~45 000 distinct gates per 256-row chunk force the LDS hash
+    """Chunks far richer than the radar geometries produce: ~45 000 distinct gates per chunk of 4 x 64 rows force the LDS hash
     set of the builder through 8-16 rounds and every chunk of the kernel onto the per-pair fallback; a chunk with more
     than 65 536 distinct gates makes the geometry non-compactable.  Hand-made CSR, compared bit for bit with the
     standard kernel and decoded back to the original indices."""

@@ -286,7 +286,7 @@ def test_c2_compact_only_layout(c2, tmp_path):
     compact = geom.device_compact(dev)
     assert torch.equal(compact.decode(csr), std.gate_indices)
     nx = cfg["grid_shape"][2]
-    r0, r1 = 7 * nx + 13, 1234 * nx + 5          # a row range that is not aligned to the 256-row chunks
+    r0, r1 = 7 * nx + 13, 1234 * nx + 5          # a row range that cuts through chunks (4 lines x 64 rows)
     assert torch.equal(compact.decode(csr, r0, r1), std.gate_indices[int(std.indptr[r0]):int(std.indptr[r1])])
     f, m = c2["fields"]["DBZH"], c2["masks"]["DBZH"]
     want = rg.grid_fields_device(c2["geom"], [f], [m])
