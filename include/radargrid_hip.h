@@ -314,7 +314,8 @@ int rg_grid_filter(const void* src, int32_t data_is_f64, int64_t n, int32_t flag
  * window_cap: how many dictionary entries (of `stride` floats) a workgroup keeps in LDS (<= RG_COMPACT_MAX_WINDOW,
  * clamped to what fits next to the kernel's own LDS); chunks with a longer dictionary gather per pair from memory, so
  * any value is correct and the choice only affects speed.  tile: pairs per pipeline step, 0 = default (= the tile of
- * rg_csr_apply_f32 for the same field count; other values change the order of the float32 adds).
+ * rg_csr_apply_f32 for the same field count; other values change the order of the float32 adds; 901-903 and
+ * multiples of 1000 added to the tile are timing-only diagnostics of tools/exp_nf1.py, never used by the package).
  * line_len <= 0 means one line of n_vox rows, lines_per_plane <= 0 one plane.
  * ------------------------------------------------------------------------------------------------- */
 #ifndef RG_COMPACT_LINES

@@ -83,7 +83,9 @@ __device__ __forceinline__ Segment chunk_segment(const ChunkGrid& g, unsigned ch
   return s;
 }
 
-template <typename IndT, int NF, int STRIDE, int TILE>
+// ABLATE (timing-only diagnostics, results wrong by construction): 1 = no row phase, 2 = no products and no row phase
+// (the values still have to be looked up: they are summed into the output), 3 = neither products, row phase nor window
+template <typename IndT, int NF, int STRIDE, int TILE, int ABLATE = 0>
 __global__ __launch_bounds__(64 * kH) void csr_compact_kernel(
     const IndT* __restrict__ indptr, const uint16_t* __restrict__ lidx, const float* __restrict__ wts,
     const int64_t* __restrict__ dict_ptr, const int32_t* __restrict__ dict, ChunkGrid cg,
@@ -188,7 +190,9 @@ __global__ __launch_bounds__(64 * kH) void csr_compact_kernel(
       for (int it = 0; it < IT; ++it) {
         const int pos = cur.ci[it] < nd_last ? cur.ci[it] : nd_last;
         if constexpr (kWindowed) {
-          if constexpr (STRIDE == 1) {
+          if constexpr (ABLATE == 3) {
+            val[it][0] = __builtin_bit_cast(float, pos);
+          } else if constexpr (STRIDE == 1) {
             val[it][0] = window[pos];
           } else if constexpr (STRIDE == 2) {
             const f32x2 q = reinterpret_cast<const f32x2*>(window)[pos];
@@ -208,14 +212,17 @@ __global__ __launch_bounds__(64 * kH) void csr_compact_kernel(
       }
       // ---- products of tile t -> LDS (layout and arithmetic: rg_row_phase.hpp) ----------------------------------
 #pragma unroll
-      for (int it = 0; it < IT; ++it) rg::store_products<NF, STRIDE>(tile, TILE, it * 64 + lane, cur.cw[it], val[it]);
+      for (int it = 0; it < IT; ++it) {
+        if constexpr (ABLATE >= 2) rowacc[lane * STRIDE].x += val[it][0] * cur.cw[it];
+        else rg::store_products<NF, STRIDE>(tile, TILE, it * 64 + lane, cur.cw[it], val[it]);
+      }
       stream(cur, t + 2 * TILE);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
       // ---- dynamic row phase (shared with rg_csr_apply_f32: same lane split, same float32 adds) ----------------
-      rg::row_phase<NF, STRIDE, TILE>(tile, rowacc, t, rs_o, re_o, lane);
+      if constexpr (ABLATE == 0) rg::row_phase<NF, STRIDE, TILE>(tile, rowacc, t, rs_o, re_o, lane);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -250,7 +257,7 @@ constexpr size_t static_lds() {
   return (size_t)kH * (TILE * rg::tile_floats(NF, stride_for(NF)) * 4 + 64 * stride_for(NF) * 8);
 }
 
-template <typename IndT, int NF, int TILE>
+template <typename IndT, int NF, int TILE, int ABLATE = 0>
 int launch_nf(int window_cap, const void* indptr, const uint16_t* lidx, const float* wts, const int64_t* dict_ptr,
               const int32_t* dict, const ChunkGrid& cg, long n_vox, const float* packed, long n_gates, float fill,
               float* out, hipStream_t s) {
@@ -259,7 +266,7 @@ int launch_nf(int window_cap, const void* indptr, const uint16_t* lidx, const fl
   // smaller than the geometry asked for only sends more chunks down the per-pair path (same results)
   const long room = (65536 - (long)static_lds<IndT, NF, TILE>() - 256) / (4 * STRIDE);
   if (window_cap > room) window_cap = (int)(room < 0 ? 0 : room);
-  hipLaunchKernelGGL((csr_compact_kernel<IndT, NF, STRIDE, TILE>), dim3((unsigned)chunk_count(cg)), dim3(64 * kH),
+  hipLaunchKernelGGL((csr_compact_kernel<IndT, NF, STRIDE, TILE, ABLATE>), dim3((unsigned)chunk_count(cg)), dim3(64 * kH),
                      (size_t)window_cap * STRIDE * sizeof(float), s, static_cast<const IndT*>(indptr), lidx, wts, dict_ptr,
                      dict, cg, packed, (unsigned)(n_gates - 1), fill, window_cap, n_vox, out);
   return rg::check_launch("rg_csr_compact_apply_f32");
@@ -275,6 +282,9 @@ int launch(int nf, int tile, int window_cap, const void* indptr, const uint16_t*
   switch (nf) {
     case 1:
       switch (tile) {
+        case 901: return launch_nf<IndT, 1, 384, 1>(window_cap, indptr, lidx, wts, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s);
+        case 902: return launch_nf<IndT, 1, 384, 2>(window_cap, indptr, lidx, wts, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s);
+        case 903: return launch_nf<IndT, 1, 384, 3>(window_cap, indptr, lidx, wts, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s);
         case 128: return RG_K1C(1, 128);
         case 256: return RG_K1C(1, 256);
         case 512: return RG_K1C(1, 512);
@@ -356,7 +366,8 @@ extern "C" int rg_csr_compact_apply_f32(const void* indptr, int32_t indptr_is_i6
   RG_REQUIRE(n_vox <= 0x3FFFFFFFFFL, RG_EUNSUPPORTED, "rg_csr_compact_apply_f32: n_vox too large for one launch");
   const int32_t rot_override = tile / 1000;   // diagnostic: tile = 1000 * rotation + tile selects the block rotation
   tile %= 1000;
-  RG_REQUIRE(tile == 0 || tile == 128 || tile == 192 || tile == 256 || tile == 320 || tile == 384 || tile == 512, RG_EINVAL,
+  RG_REQUIRE(tile == 0 || tile == 128 || tile == 192 || tile == 256 || tile == 320 || tile == 384 || tile == 512 ||
+                 (tile >= 901 && tile <= 903), RG_EINVAL,
              "rg_csr_compact_apply_f32: tile must be 0 (default), 128, 192, 256, 320, 384 or 512");
   RG_REQUIRE(window_cap >= 0 && window_cap <= RG_COMPACT_MAX_WINDOW, RG_EINVAL,
              "rg_csr_compact_apply_f32: window_cap %d outside 0..%d", window_cap, RG_COMPACT_MAX_WINDOW);
