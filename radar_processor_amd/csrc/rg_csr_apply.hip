@@ -125,7 +125,7 @@ __global__ __launch_bounds__(64 * wpb_of(FLAGS)) void csr_apply_dyn_kernel(
   constexpr int WPB = wpb_of(FLAGS);
   constexpr int NST = (FLAGS & kStages3) ? 3 : 2;   // tiles of CSR in flight per wavefront
   __shared__ __attribute__((aligned(16))) float tile_all[WPB][TILE * rg::tile_floats(NF, STRIDE)];
-  __shared__ f32x2 rowacc_all[WPB][64 * STRIDE];
+  __shared__ f32x2 rowacc_all[WPB][64 * NF];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float* tile = tile_all[wv];
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(64 * wpb_of(FLAGS)) void csr_apply_dyn_kernel(
   const int rs_o = (int)((long)indptr[r0 + (lane < nrows ? lane : nrows)] - seg_b);
   const int re_o = (int)((long)indptr[r0 + (lane + 1 < nrows ? lane + 1 : nrows)] - seg_b);
 #pragma unroll
-  for (int f = 0; f < STRIDE; ++f) rowacc[lane * STRIDE + f] = (f32x2)(0.0f);
+  for (int f = 0; f < NF; ++f) rowacc[lane * NF + f] = (f32x2)(0.0f);
 
   if (span > 0) {
     // Software pipeline over the tiles.  Stage k mod NST holds tile k's indices and weights, value set k mod NST
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(64 * wpb_of(FLAGS)) void csr_apply_dyn_kernel(
   if (lane < nrows) {
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
-      const f32x2 s = rowacc[lane * STRIDE + f];
+      const f32x2 s = rowacc[lane * NF + f];
       out[(size_t)f * n_vox + row] = s.y > 0.0f ? (float)((double)s.x / (double)s.y) : fill;
     }
   }

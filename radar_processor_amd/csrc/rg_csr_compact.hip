@@ -93,9 +93,10 @@ __global__ __launch_bounds__(64 * kH) void csr_compact_kernel(
     float* __restrict__ out) {
   static_assert(TILE % 64 == 0, "a wave handles 64 pairs per step");
   constexpr int IT = TILE / 64;
-  extern __shared__ __attribute__((aligned(16))) float window[];   // window_cap entries of STRIDE floats
+  // window_cap entries: the packed slots of a gate (STRIDE floats), except that a 3-field entry drops the padding slot
+  extern __shared__ __attribute__((aligned(16))) float window[];
   __shared__ __attribute__((aligned(16))) float tile_all[kH][TILE * rg::tile_floats(NF, STRIDE)];
-  __shared__ f32x2 rowacc_all[kH][64 * STRIDE];
+  __shared__ f32x2 rowacc_all[kH][64 * NF];
   static_assert((sizeof(tile_all) + sizeof(rowacc_all)) % 16 == 0,
                 "the dynamic window starts where the static arrays end and is accessed 16 bytes wide");
   const int lane = threadIdx.x & 63;
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(64 * kH) void csr_compact_kernel(
   const int rs_o = nrows ? (int)((long)indptr[r0 + (lane < nrows ? lane : nrows)] - seg_b) : 0;
   const int re_o = nrows ? (int)((long)indptr[r0 + (lane + 1 < nrows ? lane + 1 : nrows)] - seg_b) : 0;
 #pragma unroll
-  for (int f = 0; f < STRIDE; ++f) rowacc[lane * STRIDE + f] = (f32x2)(0.0f);
+  for (int f = 0; f < NF; ++f) rowacc[lane * NF + f] = (f32x2)(0.0f);
 
   // Two register stages, loop unrolled by two, every load unconditional and range-checked against the segment's last
   // pair -- the same exact-wait-count pipeline as rg_csr_apply_f32, without a gather stage.
@@ -169,6 +170,8 @@ __global__ __launch_bounds__(64 * kH) void csr_compact_kernel(
         window[i] = v[0];
       } else if constexpr (STRIDE == 2) {
         reinterpret_cast<f32x2*>(window)[i] = (f32x2){v[0], v[1]};
+      } else if constexpr (NF == 3) {
+        window[i * 3] = v[0]; window[i * 3 + 1] = v[1]; window[i * 3 + 2] = v[2];
       } else {
 #pragma unroll
         for (int q = 0; q < STRIDE; q += 4)
@@ -197,6 +200,9 @@ __global__ __launch_bounds__(64 * kH) void csr_compact_kernel(
           } else if constexpr (STRIDE == 2) {
             const f32x2 q = reinterpret_cast<const f32x2*>(window)[pos];
             val[it][0] = q.x; val[it][1] = q.y;
+          } else if constexpr (NF == 3) {
+            val[it][0] = window[pos * 3]; val[it][1] = window[pos * 3 + 1]; val[it][2] = window[pos * 3 + 2];
+            val[it][3] = 0.0f;   // the padding slot is never looked at
           } else {
 #pragma unroll
             for (int s = 0; s < STRIDE; s += 4) {
@@ -213,7 +219,7 @@ __global__ __launch_bounds__(64 * kH) void csr_compact_kernel(
       // ---- products of tile t -> LDS (layout and arithmetic: rg_row_phase.hpp) ----------------------------------
 #pragma unroll
       for (int it = 0; it < IT; ++it) {
-        if constexpr (ABLATE >= 2) rowacc[lane * STRIDE].x += val[it][0] * cur.cw[it];
+        if constexpr (ABLATE >= 2) rowacc[lane * NF].x += val[it][0] * cur.cw[it];
         else rg::store_products<NF, STRIDE>(tile, TILE, it * 64 + lane, cur.cw[it], val[it]);
       }
       stream(cur, t + 2 * TILE);
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(64 * kH) void csr_compact_kernel(
   if (lane < nrows) {
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
-      const f32x2 s = rowacc[lane * STRIDE + f];
+      const f32x2 s = rowacc[lane * NF + f];
       out[(size_t)f * n_vox + r0 + lane] = s.y > 0.0f ? (float)((double)s.x / (double)s.y) : fill;
     }
   }
@@ -254,7 +260,7 @@ constexpr int stride_for(int nf) { return nf == 1 ? 1 : nf == 2 ? 2 : nf <= 4 ? 
 
 template <typename IndT, int NF, int TILE>
 constexpr size_t static_lds() {
-  return (size_t)kH * (TILE * rg::tile_floats(NF, stride_for(NF)) * 4 + 64 * stride_for(NF) * 8);
+  return (size_t)kH * (TILE * rg::tile_floats(NF, stride_for(NF)) * 4 + 64 * NF * 8);
 }
 
 template <typename IndT, int NF, int TILE, int ABLATE = 0>
@@ -264,10 +270,11 @@ int launch_nf(int window_cap, const void* indptr, const uint16_t* lidx, const fl
   constexpr int STRIDE = stride_for(NF);
   // static + dynamic LDS of one workgroup stay within the 64 KiB a launch gets without opting in to more; a window
   // smaller than the geometry asked for only sends more chunks down the per-pair path (same results)
-  const long room = (65536 - (long)static_lds<IndT, NF, TILE>() - 256) / (4 * STRIDE);
+  constexpr int WS = NF == 3 ? 3 : STRIDE;   // floats per window entry (see the kernel)
+  const long room = (65536 - (long)static_lds<IndT, NF, TILE>() - 256) / (4 * WS);
   if (window_cap > room) window_cap = (int)(room < 0 ? 0 : room);
   hipLaunchKernelGGL((csr_compact_kernel<IndT, NF, STRIDE, TILE, ABLATE>), dim3((unsigned)chunk_count(cg)), dim3(64 * kH),
-                     (size_t)window_cap * STRIDE * sizeof(float), s, static_cast<const IndT*>(indptr), lidx, wts, dict_ptr,
+                     ((size_t)window_cap * WS * sizeof(float) + 15) / 16 * 16, s, static_cast<const IndT*>(indptr), lidx, wts, dict_ptr,
                      dict, cg, packed, (unsigned)(n_gates - 1), fill, window_cap, n_vox, out);
   return rg::check_launch("rg_csr_compact_apply_f32");
 }

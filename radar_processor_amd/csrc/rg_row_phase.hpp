@@ -99,7 +99,7 @@ __device__ __forceinline__ void store_products(float* __restrict__ tile, int til
 
 // ---- row side ---------------------------------------------------------------------------------------------------
 // rs_o / re_o: this lane's row = pairs [rs_o, re_o) of the segment (lane == row); t = first pair of the tile.
-// rowacc: f32x2[64 * STRIDE], entry (row, f) = running (sum w*v, sum w).
+// rowacc: f32x2[64 * NF], entry (row, f) = running (sum w*v, sum w).
 template <int NF, int STRIDE, int TILE>
 __device__ __forceinline__ void row_phase(const float* __restrict__ tile, f32x2* __restrict__ rowacc, int t, int rs_o,
                                           int re_o, int lane) {
@@ -177,7 +177,7 @@ __device__ __forceinline__ void row_phase(const float* __restrict__ tile, f32x2*
       butterfly<2 * NF>(sv, nsub);
       if (live && sub == 0) {
 #pragma unroll
-        for (int f = 0; f < NF; ++f) rowacc[myrow * STRIDE + f] += (f32x2){sv[2 * f], sv[2 * f + 1]};
+        for (int f = 0; f < NF; ++f) rowacc[myrow * NF + f] += (f32x2){sv[2 * f], sv[2 * f + 1]};
       }
     }
   }

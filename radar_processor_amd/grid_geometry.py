@@ -99,11 +99,16 @@ class CompactCSR:
         sx = (x // (base + 1)).where(x < split, extra + (x - split) // max(base, 1))
         return (plane * nyg + y // _native.RG_COMPACT_LINES) * nsx + sx
 
+    @staticmethod
+    def entry_bytes(n_fields: int) -> int:
+        """Bytes of one LDS window entry of the compact kernel: the packed slots of a gate (1, 2, 4 or 8 floats), a
+        3-field entry without its padding slot."""
+        return 4 * (1 if n_fields == 1 else 2 if n_fields == 2 else 3 if n_fields == 3 else 4 if n_fields == 4 else 8)
+
     def window_for(self, n_fields: int, lds_budget_bytes: int = 32768) -> int:
-        """LDS window (entries) for a pass of ``n_fields`` fields: the geometry's 99.9 % window if its entries
-        (4 bytes x stride) fit ``lds_budget_bytes``, else the largest that does."""
-        stride = 1 if n_fields == 1 else 2 if n_fields == 2 else 4 if n_fields <= 4 else 8
-        room = max(0, lds_budget_bytes // (4 * stride)) // 64 * 64
+        """LDS window (entries) for a pass of ``n_fields`` fields: the geometry's 99.9 % window if its entries fit
+        ``lds_budget_bytes``, else the largest that does."""
+        room = max(0, lds_budget_bytes // self.entry_bytes(n_fields)) // 64 * 64
         return int(min(self.window_cap, room))
 
     def fallback_fraction(self, window: int) -> float:

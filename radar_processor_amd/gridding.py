@@ -103,7 +103,8 @@ class CsrGridder:
         want = compact or compact_only
         self.compact = geometry.device_compact(self.dev) if (want and self.csr.n_pairs) else None
         if (self.compact is not None and not compact_only
-                and self.compact.window_for(self.n_fields) * 4 * self.stride > _COMPACT_MAX_WINDOW_BYTES):
+                and self.compact.window_for(self.n_fields) * self.compact.entry_bytes(self.n_fields)
+                > _COMPACT_MAX_WINDOW_BYTES):
             self.compact = None
         self.window = 0
         if self.compact is not None:
