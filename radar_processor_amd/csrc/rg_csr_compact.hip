@@ -85,7 +85,7 @@ __device__ __forceinline__ Segment chunk_segment(const ChunkGrid& g, unsigned ch
 
 // ABLATE (timing-only diagnostics, results wrong by construction): 1 = no row phase, 2 = no products and no row phase
 // (the values still have to be looked up: they are summed into the output), 3 = neither products, row phase nor window
-template <typename IndT, int NF, int STRIDE, int TILE, int ABLATE = 0>
+template <typename IndT, int NF, int STRIDE, int TILE, int ABLATE = 0, int AUX = 0>
 __global__ __launch_bounds__(64 * kH) void csr_compact_kernel(
     const IndT* __restrict__ indptr, const uint16_t* __restrict__ lidx, const float* __restrict__ wts,
     const int64_t* __restrict__ dict_ptr, const int32_t* __restrict__ dict, ChunkGrid cg,
@@ -151,8 +151,8 @@ __global__ __launch_bounds__(64 * kH) void csr_compact_kernel(
     const rsrc_t rw = make_rsrc(wi + t, ((long)span - t) * 4);
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
-      sgs.ci[it] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(ri, lane2 + it * 128, 0, 0);
-      sgs.cw[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, lane4 + it * 256, 0, 0));
+      sgs.ci[it] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(ri, lane2 + it * 128, 0, AUX);
+      sgs.cw[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, lane4 + it * 256, 0, AUX));
     }
   };
   // the first two tiles are requested BEFORE the window is filled: the two latencies overlap
@@ -263,7 +263,7 @@ constexpr size_t static_lds() {
   return (size_t)kH * (TILE * rg::tile_floats(NF, stride_for(NF)) * 4 + 64 * NF * 8);
 }
 
-template <typename IndT, int NF, int TILE, int ABLATE = 0>
+template <typename IndT, int NF, int TILE, int ABLATE = 0, int AUX = 0>
 int launch_nf(int window_cap, const void* indptr, const uint16_t* lidx, const float* wts, const int64_t* dict_ptr,
               const int32_t* dict, const ChunkGrid& cg, long n_vox, const float* packed, long n_gates, float fill,
               float* out, hipStream_t s) {
@@ -273,7 +273,7 @@ int launch_nf(int window_cap, const void* indptr, const uint16_t* lidx, const fl
   constexpr int WS = NF == 3 ? 3 : STRIDE;   // floats per window entry (see the kernel)
   const long room = (65536 - (long)static_lds<IndT, NF, TILE>() - 256) / (4 * WS);
   if (window_cap > room) window_cap = (int)(room < 0 ? 0 : room);
-  hipLaunchKernelGGL((csr_compact_kernel<IndT, NF, STRIDE, TILE, ABLATE>), dim3((unsigned)chunk_count(cg)), dim3(64 * kH),
+  hipLaunchKernelGGL((csr_compact_kernel<IndT, NF, STRIDE, TILE, ABLATE, AUX>), dim3((unsigned)chunk_count(cg)), dim3(64 * kH),
                      ((size_t)window_cap * WS * sizeof(float) + 15) / 16 * 16, s, static_cast<const IndT*>(indptr), lidx, wts, dict_ptr,
                      dict, cg, packed, (unsigned)(n_gates - 1), fill, window_cap, n_vox, out);
   return rg::check_launch("rg_csr_compact_apply_f32");
@@ -292,6 +292,11 @@ int launch(int nf, int tile, int window_cap, const void* indptr, const uint16_t*
         case 901: return launch_nf<IndT, 1, 384, 1>(window_cap, indptr, lidx, wts, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s);
         case 902: return launch_nf<IndT, 1, 384, 2>(window_cap, indptr, lidx, wts, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s);
         case 903: return launch_nf<IndT, 1, 384, 3>(window_cap, indptr, lidx, wts, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s);
+        case 904: return launch_nf<IndT, 1, 384, 3, 2>(window_cap, indptr, lidx, wts, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s);
+        case 905: return launch_nf<IndT, 1, 384, 0, 2>(window_cap, indptr, lidx, wts, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s);
+        case 906: return launch_nf<IndT, 1, 384, 0, 1>(window_cap, indptr, lidx, wts, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s);
+        case 907: return launch_nf<IndT, 1, 384, 0, 3>(window_cap, indptr, lidx, wts, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s);
+        case 908: return launch_nf<IndT, 1, 512, 3>(window_cap, indptr, lidx, wts, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s);
         case 128: return RG_K1C(1, 128);
         case 256: return RG_K1C(1, 256);
         case 512: return RG_K1C(1, 512);
@@ -374,7 +379,7 @@ extern "C" int rg_csr_compact_apply_f32(const void* indptr, int32_t indptr_is_i6
   const int32_t rot_override = tile / 1000;   // diagnostic: tile = 1000 * rotation + tile selects the block rotation
   tile %= 1000;
   RG_REQUIRE(tile == 0 || tile == 128 || tile == 192 || tile == 256 || tile == 320 || tile == 384 || tile == 512 ||
-                 (tile >= 901 && tile <= 903), RG_EINVAL,
+                 (tile >= 901 && tile <= 908), RG_EINVAL,
              "rg_csr_compact_apply_f32: tile must be 0 (default), 128, 192, 256, 320, 384 or 512");
   RG_REQUIRE(window_cap >= 0 && window_cap <= RG_COMPACT_MAX_WINDOW, RG_EINVAL,
              "rg_csr_compact_apply_f32: window_cap %d outside 0..%d", window_cap, RG_COMPACT_MAX_WINDOW);
