@@ -160,7 +160,7 @@ __global__ __launch_bounds__(64 * kH) void csr_compact_kernel(
   stream(st[1], TILE);
 
   // ---- the chunk's field window: one gather per DISTINCT gate --------------------------------------------
-  if (windowed) {
+  if (windowed && ABLATE != 4) {
     for (int i = threadIdx.x; i < nd_all; i += 64 * kH) {
       const unsigned g0 = (unsigned)cdict[i];
       const unsigned g = g0 < last_gate ? g0 : last_gate;   // clamp: never fault
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(64 * kH) void csr_compact_kernel(
       }
     }
   }
-  __syncthreads();
+  if constexpr (ABLATE != 4) __syncthreads();
 
   // The tile loop exists twice -- values from the LDS window, or (over-wide chunk) position -> gate -> value from memory
   // -- selected once per workgroup: a uniform branch INSIDE the unrolled loads made this compiler drop the register
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64 * kH) void csr_compact_kernel(
       for (int it = 0; it < IT; ++it) {
         const int pos = cur.ci[it] < nd_last ? cur.ci[it] : nd_last;
         if constexpr (kWindowed) {
-          if constexpr (ABLATE == 3) {
+          if constexpr (ABLATE >= 3) {
             val[it][0] = __builtin_bit_cast(float, pos);
           } else if constexpr (STRIDE == 1) {
             val[it][0] = window[pos];
@@ -292,6 +292,7 @@ int launch(int nf, int tile, int window_cap, const void* indptr, const uint16_t*
         case 901: return launch_nf<IndT, 1, 384, 1>(window_cap, indptr, lidx, wts, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s);
         case 902: return launch_nf<IndT, 1, 384, 2>(window_cap, indptr, lidx, wts, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s);
         case 903: return launch_nf<IndT, 1, 384, 3>(window_cap, indptr, lidx, wts, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s);
+        case 909: return launch_nf<IndT, 1, 384, 4>(window_cap, indptr, lidx, wts, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s);
         case 904: return launch_nf<IndT, 1, 384, 3, 2>(window_cap, indptr, lidx, wts, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s);
         case 905: return launch_nf<IndT, 1, 384, 0, 2>(window_cap, indptr, lidx, wts, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s);
         case 906: return launch_nf<IndT, 1, 384, 0, 1>(window_cap, indptr, lidx, wts, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s);
@@ -379,7 +380,7 @@ extern "C" int rg_csr_compact_apply_f32(const void* indptr, int32_t indptr_is_i6
   const int32_t rot_override = tile / 1000;   // diagnostic: tile = 1000 * rotation + tile selects the block rotation
   tile %= 1000;
   RG_REQUIRE(tile == 0 || tile == 128 || tile == 192 || tile == 256 || tile == 320 || tile == 384 || tile == 512 ||
-                 (tile >= 901 && tile <= 908), RG_EINVAL,
+                 (tile >= 901 && tile <= 909), RG_EINVAL,
              "rg_csr_compact_apply_f32: tile must be 0 (default), 128, 192, 256, 320, 384 or 512");
   RG_REQUIRE(window_cap >= 0 && window_cap <= RG_COMPACT_MAX_WINDOW, RG_EINVAL,
              "rg_csr_compact_apply_f32: window_cap %d outside 0..%d", window_cap, RG_COMPACT_MAX_WINDOW);
