@@ -146,6 +146,44 @@ def test_apply_geometry_matches_reference(rg, name):
             _assert_grid_close(multi[fname], ref[key], _atol(data, mask))
 
 
+@pytest.mark.parametrize("name", golden_names("g2_") + golden_names("g3_") + golden_names("g6_"))
+def test_compact_kernel_matches_reference(rg, name):
+    """rg_csr_compact_apply_f32 (the kernel bench.py times) fed the compact copy of the REFERENCE's CSR, against the
+    reference's gridded outputs directly -- single-field passes and the fused multi-field pass -- and bit for bit
+    against rg_csr_apply_f32 on the same CSR."""
+    import torch
+    from radar_processor_amd.gridding import CsrGridder
+    meta, ref = load_golden(name)
+    vol = volume_for(meta)
+    geom = _ref_geometry(rg, name, meta, ref)
+    dev = torch.device("cuda", 0)
+    if geom.device_csr(dev).n_pairs == 0:
+        pytest.skip("fixture without pairs")
+    compact = geom.device_compact(dev)
+    assert compact is not None
+    assert torch.equal(compact.decode(geom.device_csr(dev)), geom.device_csr(dev).gate_indices)
+    names = list(meta["fields"])
+    data_mask = [oracle.merge_masks(vol.fields[f]) for f in names]
+    f_t = [torch.from_numpy(np.ascontiguousarray(d)).to(dev) for d, _ in data_mask]
+    m_t = [torch.from_numpy(m.astype(np.uint8)).to(dev) for _, m in data_mask]
+    shape = tuple(meta["grid_shape"])
+    groups = [[i] for i in range(len(names))] + ([list(range(len(names)))] if len(names) > 1 else [])
+    for group in groups:
+        nf = len(group)
+        g_c = CsrGridder(geom, f_t[0].numel(), nf, device=dev)
+        g_c.compact, g_c.window = compact, compact.window_for(nf)          # force the copy: these windows are tiny
+        g_s = CsrGridder(geom, f_t[0].numel(), nf, device=dev)
+        assert g_s.compact is None
+        fl, ml = [f_t[i] for i in group], [m_t[i] for i in group]
+        g_c.pack(fl, ml); g_s.pack(fl, ml)
+        got = torch.empty((nf, g_c.n_vox), dtype=torch.float32, device=dev)
+        std = torch.empty_like(got)
+        g_c.apply(got); g_s.apply(std)
+        assert torch.equal(got.view(torch.int32), std.view(torch.int32))
+        for k, i in enumerate(group):
+            _assert_grid_close(got[k].cpu().numpy().reshape(shape), ref[f"grid_{names[i]}"], _atol(*data_mask[i]))
+
+
 def test_reference_grid_relative_error(rg):
     """north_star's bar is "<= 1e-5 relative fp32".  Both sides multiply and sum in float32 but in different orders, so
     the comparison above carries an absolute floor (1e-5 * max|field|) for weighted means that cancel to ~0.  This test
