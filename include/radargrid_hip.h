@@ -328,6 +328,25 @@ int rg_csr_compact_apply_f32(const void* indptr, int32_t indptr_is_i64, const ui
                              int32_t stride, int64_t n_gates, float fill_value, float* out, int32_t window_cap,
                              int32_t tile, rg_stream_t stream);
 
+/* Packed pair stream of the compact copy (single-field passes): positions and weights of three consecutive pairs of a
+ * segment in one 16-byte record -- 5.33 bytes per pair instead of 6, streamed with one 16-byte load per lane.
+ *   record = [w0:26 | p2 bits 0-5] [w1:26 | p2 bits 6-11] [w2:26 | p2 bits 12-15] [p0:16 | p1:16]   (4 x uint32)
+ *   weight code = float32 bits of the weight - w_base; the caller guarantees that every code fits 26 bits (all weights
+ *   positive and within 8 binades of w_base >> 23), which makes the coding lossless.
+ * Segments (the <= 64 rows one wavefront owns) are numbered line-major, seg = line * ceil(line_len / 64) + sx; segment
+ * seg owns records rec_ptr[seg] .. rec_ptr[seg+1], ceil(pairs / 3) of them (rec_ptr has segments + 1 entries, built by the
+ * caller).  rg_csr_compact_pack fills `records` from local_idx + weights; rg_csr_compact_apply_packed_f32 grids 1-4 fused
+ * fields through them: the results of rg_csr_compact_apply_f32 / rg_csr_apply_f32 for the same fields, bit for bit. */
+int rg_csr_compact_pack(const void* indptr, int32_t indptr_is_i64, const uint16_t* local_idx, const float* weights,
+                        int64_t n_rows, int64_t line_len, int64_t lines_per_plane, const int64_t* rec_ptr,
+                        uint32_t w_base, void* records, int32_t* error_flag, rg_stream_t stream);
+int rg_csr_compact_apply_packed_f32(const void* indptr, int32_t indptr_is_i64, const void* records,
+                                    const int64_t* rec_ptr, uint32_t w_base, const int64_t* dict_ptr,
+                                    const int32_t* dict, int64_t n_vox, int64_t n_pairs, int64_t line_len,
+                                    int64_t lines_per_plane, const float* packed, int32_t n_fields, int32_t stride,
+                                    int64_t n_gates, float fill_value, float* out, int32_t window_cap,
+                                    rg_stream_t stream);
+
 /* number of chunks of a grid of n_rows rows (negative rg_status when the sizes do not factor) */
 int64_t rg_csr_compact_chunks(int64_t n_rows, int64_t line_len, int64_t lines_per_plane);
 

@@ -289,23 +289,26 @@ int dispatch(int nf, int variant, const void* indptr, const int32_t* gidx, const
     case 2:
       switch (variant) {
         case 128: return RG_KD(2, 2, 128, kXcdNone, 0);
+        case 256: return RG_KD(2, 2, 256, kXcdNone, 0);
         case 512: return RG_KD(2, 2, 512, kXcdNone, 0);
-        default: return RG_KD(2, 2, 256, kXcdNone, 0);
+        default: return RG_KD(2, 2, 384, kXcdNone, 0);
       }
     case 3:
       switch (variant) {
         case 128: return RG_KD(3, 4, 128, kXcdNone, 0);
         case 192: return RG_KD(3, 4, 192, kXcdNone, 0);
         case 256: return RG_KD(3, 4, 256, kXcdNone, 0);
-        case 384: return RG_KD(3, 4, 384, kXcdNone, 0);
-        default: return RG_KD(3, 4, 320, kXcdNone, 0);   // config 2 / bench grid, ms: 256 -> 2.48 / 17.5, 320 -> 2.37 / 16.9, 384 -> 2.39 / 17.1
+        case 320: return RG_KD(3, 4, 320, kXcdNone, 0);
+        // config 2 / bench grid, ms: 256 -> 2.48 / 17.5, 320 -> 2.37 / 16.9, 384 -> 2.39 / 17.1; 384 = 2 x 192 pairs is
+        // also what the packed stream of the compact kernel needs (same tile = same bits)
+        default: return RG_KD(3, 4, 384, kXcdNone, 0);
       }
     case 4:
       switch (variant) {
         case 128: return RG_KD(4, 4, 128, kXcdNone, 0);
         case 256: return RG_KD(4, 4, 256, kXcdNone, 0);
-        case 384: return RG_KD(4, 4, 384, kXcdNone, 0);
-        default: return RG_KD(4, 4, 320, kXcdNone, 0);
+        case 320: return RG_KD(4, 4, 320, kXcdNone, 0);
+        default: return RG_KD(4, 4, 384, kXcdNone, 0);
       }
     case 5: return RG_KD(5, 8, 128, kXcdNone, 0);
     case 6: return RG_KD(6, 8, 128, kXcdNone, 0);

@@ -30,6 +30,12 @@
 #include "rg_common.hpp"
 #include "rg_row_phase.hpp"
 
+// 16-byte buffer load by intrinsic name (this compiler's __builtin_amdgcn_raw_buffer_load_b128 returns the first dword
+// in every element, see rg_csr_apply.hip); namespace scope: a name bound to an intrinsic must not have internal linkage.
+using rg_u32x4 = unsigned __attribute__((ext_vector_type(4)));
+__device__ rg_u32x4 rg_buffer_load_v4u32(__amdgpu_buffer_rsrc_t, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.raw.ptr.buffer.load.v4i32");
+
 namespace {
 
 using rg::f32x2;
@@ -62,6 +68,7 @@ __host__ __device__ inline long chunk_count(const ChunkGrid& g) { return g.n_pla
 
 struct Segment {
   long r0;      // first row
+  long seg;     // segment number, line-major: (plane * lines_per_plane + line) * nsx + sx
   int nrows;    // 0 for a wavefront past the last line of the plane
 };
 
@@ -74,9 +81,11 @@ __device__ __forceinline__ Segment chunk_segment(const ChunkGrid& g, unsigned ch
   Segment s;
   if (y >= g.lines_per_plane) {
     s.r0 = 0;
+    s.seg = 0;
     s.nrows = 0;
     return s;
   }
+  s.seg = ((long)plane * g.lines_per_plane + y) * g.nsx + sx;
   const unsigned x0 = sx * g.seg_base + (sx < g.seg_extra ? sx : g.seg_extra);
   s.r0 = ((long)plane * g.lines_per_plane + y) * g.line_len + (long)x0;
   s.nrows = (int)(g.seg_base + (sx < g.seg_extra ? 1u : 0u));
@@ -85,13 +94,16 @@ __device__ __forceinline__ Segment chunk_segment(const ChunkGrid& g, unsigned ch
 
 // ABLATE (timing-only diagnostics, results wrong by construction): 1 = no row phase, 2 = no products and no row phase
 // (the values still have to be looked up: they are summed into the output), 3 = neither products, row phase nor window
-template <typename IndT, int NF, int STRIDE, int TILE, int ABLATE = 0, int AUX = 0>
+// PACKED: positions and weights come from 16-byte records of three pairs each (see rg_csr_compact_pack) instead of the
+// 2-byte position and 4-byte weight arrays: 5.33 instead of 6 bytes per pair, one dwordx4 per lane and 192 pairs.
+template <typename IndT, int NF, int STRIDE, int TILE, int ABLATE = 0, int AUX = 0, bool PACKED = false>
 __global__ __launch_bounds__(64 * kH) void csr_compact_kernel(
     const IndT* __restrict__ indptr, const uint16_t* __restrict__ lidx, const float* __restrict__ wts,
     const int64_t* __restrict__ dict_ptr, const int32_t* __restrict__ dict, ChunkGrid cg,
     const float* __restrict__ packed, unsigned last_gate, float fill, int window_cap, long n_vox,
-    float* __restrict__ out) {
+    float* __restrict__ out, const rg_u32x4* __restrict__ rec, const int64_t* __restrict__ rec_ptr, unsigned w_base) {
   static_assert(TILE % 64 == 0, "a wave handles 64 pairs per step");
+  static_assert(!PACKED || TILE % 192 == 0, "a packed tile is whole wave-loads of 64 three-pair records");
   constexpr int IT = TILE / 64;
   // window_cap entries: the packed slots of a gate (STRIDE floats), except that a 3-field entry drops the padding slot
   extern __shared__ __attribute__((aligned(16))) float window[];
@@ -138,23 +150,65 @@ __global__ __launch_bounds__(64 * kH) void csr_compact_kernel(
 
   // Two register stages, loop unrolled by two, every load unconditional and range-checked against the segment's last
   // pair -- the same exact-wait-count pipeline as rg_csr_apply_f32, without a gather stage.
-  struct Stage {
+  struct StagePlain {
     int ci[IT];
     float cw[IT];
   };
+  struct StagePacked {
+    rg_u32x4 r[PACKED ? IT / 3 : 1];
+  };
+  using Stage = std::conditional_t<PACKED, StagePacked, StagePlain>;
   Stage st[2];
   const uint16_t* __restrict__ li = lidx + seg_b;
   const float* __restrict__ wi = wts + seg_b;
   const int lane2 = lane * 2, lane4 = lane * 4;
+  long rec_b = 0, rec_n = 0;                 // this segment's records (PACKED)
+  if constexpr (PACKED) {
+    if (nrows) {
+      rec_b = rec_ptr[sg.seg];
+      rec_n = rec_ptr[sg.seg + 1] - rec_b;
+    }
+  }
   auto stream = [&](Stage& sgs, int t) {   // t wave-uniform: the resources live in SGPRs
-    const rsrc_t ri = make_rsrc(li + t, ((long)span - t) * 2);
-    const rsrc_t rw = make_rsrc(wi + t, ((long)span - t) * 4);
+    if constexpr (PACKED) {
+      const long r_t = t / 3;               // tiles are multiples of 192 pairs = 64 records
+      const rsrc_t rr = make_rsrc(rec + rec_b + r_t, (rec_n - r_t) * 16);
 #pragma unroll
-    for (int it = 0; it < IT; ++it) {
-      sgs.ci[it] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(ri, lane2 + it * 128, 0, AUX);
-      sgs.cw[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, lane4 + it * 256, 0, AUX));
+      for (int k = 0; k < IT / 3; ++k) sgs.r[k] = rg_buffer_load_v4u32(rr, lane * 16 + k * 1024, 0, AUX);
+    } else {
+      const rsrc_t ri = make_rsrc(li + t, ((long)span - t) * 2);
+      const rsrc_t rw = make_rsrc(wi + t, ((long)span - t) * 4);
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        sgs.ci[it] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(ri, lane2 + it * 128, 0, AUX);
+        sgs.cw[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, lane4 + it * 256, 0, AUX));
+      }
     }
   };
+  // pair slot `it` of a stage -> (position, weight) and its index in the tile.  Plain: pair it*64 + lane.  Packed: lane
+  // holds record k = it / 3 of the tile's k-th wave-load, i.e. pairs k*192 + 3*lane + (it % 3); a record is
+  // [w0:26 | p2[0:6]] [w1:26 | p2[6:12]] [w2:26 | p2[12:16]] [p0:16 | p1:16], w = float32 bits minus w_base.
+  auto decode = [&](const Stage& sgs, int (&ci)[IT], float (&cw)[IT]) {
+    if constexpr (PACKED) {
+#pragma unroll
+      for (int k = 0; k < IT / 3; ++k) {
+        const rg_u32x4 q = sgs.r[k];
+        cw[3 * k] = __builtin_bit_cast(float, (q.x & 0x3FFFFFFu) + w_base);
+        cw[3 * k + 1] = __builtin_bit_cast(float, (q.y & 0x3FFFFFFu) + w_base);
+        cw[3 * k + 2] = __builtin_bit_cast(float, (q.z & 0x3FFFFFFu) + w_base);
+        ci[3 * k] = (int)(q.w & 0xFFFFu);
+        ci[3 * k + 1] = (int)(q.w >> 16);
+        ci[3 * k + 2] = (int)((q.x >> 26) | ((q.y >> 26) << 6) | ((q.z >> 26) << 12));
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        ci[it] = sgs.ci[it];
+        cw[it] = sgs.cw[it];
+      }
+    }
+  };
+  auto eidx = [&](int it) -> int { return PACKED ? (it / 3) * 192 + 3 * lane + (it % 3) : it * 64 + lane; };
   // the first two tiles are requested BEFORE the window is filled: the two latencies overlap
   stream(st[0], 0);
   stream(st[1], TILE);
@@ -189,9 +243,12 @@ __global__ __launch_bounds__(64 * kH) void csr_compact_kernel(
     auto step = [&](int t, Stage& cur) {
       // ---- values of tile t ---------------------------------------------------------------------------------
       float val[IT][STRIDE];
+      int ci[IT];
+      float cw[IT];
+      decode(cur, ci, cw);
 #pragma unroll
       for (int it = 0; it < IT; ++it) {
-        const int pos = cur.ci[it] < nd_last ? cur.ci[it] : nd_last;
+        const int pos = ci[it] < nd_last ? ci[it] : nd_last;
         if constexpr (kWindowed) {
           if constexpr (ABLATE >= 3) {
             val[it][0] = __builtin_bit_cast(float, pos);
@@ -219,8 +276,8 @@ __global__ __launch_bounds__(64 * kH) void csr_compact_kernel(
       // ---- products of tile t -> LDS (layout and arithmetic: rg_row_phase.hpp) ----------------------------------
 #pragma unroll
       for (int it = 0; it < IT; ++it) {
-        if constexpr (ABLATE >= 2) rowacc[lane * NF].x += val[it][0] * cur.cw[it];
-        else rg::store_products<NF, STRIDE>(tile, TILE, it * 64 + lane, cur.cw[it], val[it]);
+        if constexpr (ABLATE >= 2) rowacc[lane * NF].x += val[it][0] * cw[it];
+        else rg::store_products<NF, STRIDE>(tile, TILE, eidx(it), cw[it], val[it]);
       }
       stream(cur, t + 2 * TILE);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -263,19 +320,26 @@ constexpr size_t static_lds() {
   return (size_t)kH * (TILE * rg::tile_floats(NF, stride_for(NF)) * 4 + 64 * NF * 8);
 }
 
-template <typename IndT, int NF, int TILE, int ABLATE = 0, int AUX = 0>
+struct PackedStream {   // the packed form of positions + weights (rg_csr_compact_pack); null = the plain arrays
+  const rg_u32x4* rec = nullptr;
+  const int64_t* rec_ptr = nullptr;
+  unsigned w_base = 0;
+};
+
+template <typename IndT, int NF, int TILE, int ABLATE = 0, int AUX = 0, bool PACKED = false>
 int launch_nf(int window_cap, const void* indptr, const uint16_t* lidx, const float* wts, const int64_t* dict_ptr,
               const int32_t* dict, const ChunkGrid& cg, long n_vox, const float* packed, long n_gates, float fill,
-              float* out, hipStream_t s) {
+              float* out, hipStream_t s, PackedStream ps = PackedStream()) {
   constexpr int STRIDE = stride_for(NF);
   // static + dynamic LDS of one workgroup stay within the 64 KiB a launch gets without opting in to more; a window
   // smaller than the geometry asked for only sends more chunks down the per-pair path (same results)
   constexpr int WS = NF == 3 ? 3 : STRIDE;   // floats per window entry (see the kernel)
   const long room = (65536 - (long)static_lds<IndT, NF, TILE>() - 256) / (4 * WS);
   if (window_cap > room) window_cap = (int)(room < 0 ? 0 : room);
-  hipLaunchKernelGGL((csr_compact_kernel<IndT, NF, STRIDE, TILE, ABLATE, AUX>), dim3((unsigned)chunk_count(cg)), dim3(64 * kH),
-                     ((size_t)window_cap * WS * sizeof(float) + 15) / 16 * 16, s, static_cast<const IndT*>(indptr), lidx, wts, dict_ptr,
-                     dict, cg, packed, (unsigned)(n_gates - 1), fill, window_cap, n_vox, out);
+  hipLaunchKernelGGL((csr_compact_kernel<IndT, NF, STRIDE, TILE, ABLATE, AUX, PACKED>), dim3((unsigned)chunk_count(cg)),
+                     dim3(64 * kH), ((size_t)window_cap * WS * sizeof(float) + 15) / 16 * 16, s,
+                     static_cast<const IndT*>(indptr), lidx, wts, dict_ptr, dict, cg, packed, (unsigned)(n_gates - 1), fill,
+                     window_cap, n_vox, out, ps.rec, ps.rec_ptr, ps.w_base);
   return rg::check_launch("rg_csr_compact_apply_f32");
 }
 
@@ -306,23 +370,24 @@ int launch(int nf, int tile, int window_cap, const void* indptr, const uint16_t*
     case 2:
       switch (tile) {
         case 128: return RG_K1C(2, 128);
+        case 256: return RG_K1C(2, 256);
         case 512: return RG_K1C(2, 512);
-        default: return RG_K1C(2, 256);
+        default: return RG_K1C(2, 384);
       }
     case 3:
       switch (tile) {
         case 128: return RG_K1C(3, 128);
         case 192: return RG_K1C(3, 192);
         case 256: return RG_K1C(3, 256);
-        case 384: return RG_K1C(3, 384);
-        default: return RG_K1C(3, 320);
+        case 320: return RG_K1C(3, 320);
+        default: return RG_K1C(3, 384);
       }
     case 4:
       switch (tile) {
         case 128: return RG_K1C(4, 128);
         case 256: return RG_K1C(4, 256);
-        case 384: return RG_K1C(4, 384);
-        default: return RG_K1C(4, 320);
+        case 320: return RG_K1C(4, 320);
+        default: return RG_K1C(4, 384);
       }
     case 5: return RG_K1C(5, 128);
     case 6: return RG_K1C(6, 128);
@@ -398,6 +463,139 @@ extern "C" int rg_csr_compact_apply_f32(const void* indptr, int32_t indptr_is_i6
                            n_gates, fill_value, out, s);
   return launch<int32_t>(n_fields, tile, window_cap, indptr, local_idx, weights, dict_ptr, dict, cg, n_vox, packed, n_gates,
                          fill_value, out, s);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Packed pair stream: positions AND weights of three consecutive pairs of a segment in one 16-byte record.
+//   weight code = float32 bits of the weight minus w_base (= smallest exponent among the geometry's weights << 23); it
+//   must fit 26 bits, i.e. all weights positive and within 8 binades -- Barnes weights span exp(-4)+1e-5 .. 1+1e-5, 7
+//   binades; the host checks and falls back to the plain arrays otherwise.  Lossless: the kernel adds w_base back.
+//   record = [w0:26 | p2 bits 0-5] [w1:26 | p2 bits 6-11] [w2:26 | p2 bits 12-15] [p0:16 | p1:16]
+//   Every segment (one wavefront's rows) starts a new record; rec_ptr[seg] = its first record, segments numbered
+//   line-major (line * ceil(line_len / 64) + sx).  5.33 bytes per pair instead of 6, and the kernel streams them with one
+//   dwordx4 per lane and 192 pairs instead of six 2- and 4-byte loads.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+template <typename IndT>
+__global__ __launch_bounds__(256) void compact_pack_kernel(const IndT* __restrict__ indptr,
+                                                            const uint16_t* __restrict__ lidx,
+                                                            const float* __restrict__ wts, ChunkGrid cg, long n_seg,
+                                                            const int64_t* __restrict__ rec_ptr, unsigned w_base,
+                                                            rg_u32x4* __restrict__ rec, int32_t* __restrict__ error_flag) {
+  const int lane = threadIdx.x & 63;
+  const long seg = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (seg >= n_seg) return;
+  const long line = seg / cg.nsx;
+  const unsigned sx = (unsigned)(seg - line * cg.nsx);
+  const unsigned x0 = sx * cg.seg_base + (sx < cg.seg_extra ? sx : cg.seg_extra);
+  const long r0 = line * cg.line_len + x0;
+  const int nrows = (int)(cg.seg_base + (sx < cg.seg_extra ? 1u : 0u));
+  const long p0 = (long)indptr[r0], p1 = (long)indptr[r0 + nrows];
+  const long rb = rec_ptr[seg], rn = rec_ptr[seg + 1] - rb;
+  if (lane == 0 && rn != (p1 - p0 + 2) / 3) atomicOr(error_flag, 1);
+  for (long r = lane; r < rn; r += 64) {
+    unsigned code[3], pos[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const long p = p0 + 3 * r + j;
+      code[j] = 0;
+      pos[j] = 0;
+      if (p < p1) {
+        const unsigned bits = rg::f32_bits(wts[p]);
+        code[j] = bits - w_base;
+        if (bits < w_base || code[j] > 0x3FFFFFFu) atomicOr(error_flag, 2);   // not codable: the host checked, so never
+        pos[j] = lidx[p];
+      }
+    }
+    rg_u32x4 q;
+    q.x = (code[0] & 0x3FFFFFFu) | ((pos[2] & 0x3Fu) << 26);
+    q.y = (code[1] & 0x3FFFFFFu) | (((pos[2] >> 6) & 0x3Fu) << 26);
+    q.z = (code[2] & 0x3FFFFFFu) | (((pos[2] >> 12) & 0xFu) << 26);
+    q.w = pos[0] | (pos[1] << 16);
+    rec[rb + r] = q;
+  }
+}
+
+}  // namespace
+
+extern "C" int rg_csr_compact_pack(const void* indptr, int32_t indptr_is_i64, const uint16_t* local_idx,
+                                   const float* weights, int64_t n_rows, int64_t line_len, int64_t lines_per_plane,
+                                   const int64_t* rec_ptr, uint32_t w_base, void* records, int32_t* error_flag,
+                                   rg_stream_t stream) {
+  RG_REQUIRE(n_rows >= 0, RG_EINVAL, "rg_csr_compact_pack: negative size");
+  if (n_rows == 0) return RG_OK;
+  RG_REQUIRE(indptr && rec_ptr && error_flag, RG_EINVAL, "rg_csr_compact_pack: null pointer");
+  RG_REQUIRE(rg::aligned16(records), RG_EALIGN, "rg_csr_compact_pack: records must be 16-byte aligned");
+  ChunkGrid cg;
+  RG_REQUIRE(make_chunk_grid(n_rows, line_len, lines_per_plane, &cg), RG_EINVAL,
+             "rg_csr_compact_pack: n_rows=%ld is not planes x lines_per_plane=%ld x line_len=%ld", (long)n_rows,
+             (long)lines_per_plane, (long)line_len);
+  const long n_seg = cg.n_planes * cg.lines_per_plane * (long)cg.nsx;
+  const long blocks = (n_seg + 3) / 4;
+  RG_REQUIRE(blocks <= 0x7FFFFFFFL, RG_EUNSUPPORTED, "rg_csr_compact_pack: too many segments for one launch");
+  hipStream_t s = (hipStream_t)stream;
+  if (indptr_is_i64)
+    hipLaunchKernelGGL(compact_pack_kernel<int64_t>, dim3((unsigned)blocks), dim3(256), 0, s,
+                       static_cast<const int64_t*>(indptr), local_idx, weights, cg, n_seg, rec_ptr, w_base,
+                       static_cast<rg_u32x4*>(records), error_flag);
+  else
+    hipLaunchKernelGGL(compact_pack_kernel<int32_t>, dim3((unsigned)blocks), dim3(256), 0, s,
+                       static_cast<const int32_t*>(indptr), local_idx, weights, cg, n_seg, rec_ptr, w_base,
+                       static_cast<rg_u32x4*>(records), error_flag);
+  return rg::check_launch("rg_csr_compact_pack");
+}
+
+// 1-4 fused fields over the packed stream (same results as rg_csr_compact_apply_f32 / rg_csr_apply_f32, bit for bit)
+extern "C" int rg_csr_compact_apply_packed_f32(const void* indptr, int32_t indptr_is_i64, const void* records,
+                                               const int64_t* rec_ptr, uint32_t w_base, const int64_t* dict_ptr,
+                                               const int32_t* dict, int64_t n_vox, int64_t n_pairs, int64_t line_len,
+                                               int64_t lines_per_plane, const float* packed, int32_t n_fields,
+                                               int32_t stride, int64_t n_gates, float fill_value, float* out,
+                                               int32_t window_cap, rg_stream_t stream) {
+  RG_REQUIRE(n_fields >= 1 && n_fields <= 4, RG_EUNSUPPORTED,
+             "rg_csr_compact_apply_packed_f32: n_fields=%d not in 1..4 (5-8 fields use 128-pair tiles, not a whole number "
+             "of 64-record loads)", n_fields);
+  RG_REQUIRE(stride == stride_for(n_fields), RG_EINVAL, "rg_csr_compact_apply_packed_f32: stride=%d, expected %d for %d fields",
+             stride, stride_for(n_fields), n_fields);
+  RG_REQUIRE(indptr && out && dict_ptr && rec_ptr, RG_EINVAL, "rg_csr_compact_apply_packed_f32: null indptr/dict_ptr/rec_ptr/out");
+  RG_REQUIRE(n_vox >= 0 && n_pairs >= 0, RG_EINVAL, "rg_csr_compact_apply_packed_f32: negative size");
+  RG_REQUIRE(n_pairs == 0 || (records && dict && packed && n_gates > 0), RG_EINVAL,
+             "rg_csr_compact_apply_packed_f32: pairs present but records/dict/packed/n_gates missing");
+  RG_REQUIRE(n_gates <= 0x7FFFFFFFL, RG_EUNSUPPORTED, "rg_csr_compact_apply_packed_f32: n_gates exceeds int32 gate indices");
+  RG_REQUIRE(n_vox <= 0x3FFFFFFFFFL, RG_EUNSUPPORTED, "rg_csr_compact_apply_packed_f32: n_vox too large for one launch");
+  RG_REQUIRE(window_cap >= 0 && window_cap <= RG_COMPACT_MAX_WINDOW, RG_EINVAL,
+             "rg_csr_compact_apply_packed_f32: window_cap %d outside 0..%d", window_cap, RG_COMPACT_MAX_WINDOW);
+  RG_REQUIRE(rg::aligned16(records), RG_EALIGN, "rg_csr_compact_apply_packed_f32: records must be 16-byte aligned");
+  if (n_vox == 0) return RG_OK;
+  ChunkGrid cg;
+  RG_REQUIRE(make_chunk_grid(n_vox, line_len, lines_per_plane, &cg), RG_EINVAL,
+             "rg_csr_compact_apply_packed_f32: n_vox=%ld is not planes x lines_per_plane=%ld x line_len=%ld", (long)n_vox,
+             (long)lines_per_plane, (long)line_len);
+  RG_REQUIRE(chunk_count(cg) <= 0x7FFFFFFFL, RG_EUNSUPPORTED, "rg_csr_compact_apply_packed_f32: too many chunks for one launch");
+  PackedStream ps;
+  ps.rec = static_cast<const rg_u32x4*>(records);
+  ps.rec_ptr = rec_ptr;
+  ps.w_base = w_base;
+  hipStream_t s = (hipStream_t)stream;
+#define RG_K1P(IND_, NF_)                                                                                              \
+  launch_nf<IND_, NF_, 384, 0, 0, true>(window_cap, indptr, nullptr, nullptr, dict_ptr, dict, cg, n_vox, packed, n_gates, \
+                                        fill_value, out, s, ps)
+  if (indptr_is_i64) {
+    switch (n_fields) {
+      case 1: return RG_K1P(int64_t, 1);
+      case 2: return RG_K1P(int64_t, 2);
+      case 3: return RG_K1P(int64_t, 3);
+      default: return RG_K1P(int64_t, 4);
+    }
+  }
+  switch (n_fields) {
+    case 1: return RG_K1P(int32_t, 1);
+    case 2: return RG_K1P(int32_t, 2);
+    case 3: return RG_K1P(int32_t, 3);
+    default: return RG_K1P(int32_t, 4);
+  }
+#undef RG_K1P
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -70,7 +70,7 @@ class CsrGridder:
     """
 
     def __init__(self, geometry: GridGeometry, n_gates: int, n_fields: int, device=None, compact: bool = False,
-                 tile: int = 0):
+                 tile: int = 0, packed: bool = True):
         """``compact``: run the pass through the compact device copy of the CSR (``rg_csr_compact_apply_f32``, built
         and cached on the geometry the first time) when the geometry allows one and its LDS window for this field count
         covers (nearly) all pairs; results are identical, bit for bit.  ``tile``: diagnostic override of the pipeline
@@ -112,6 +112,10 @@ class CsrGridder:
             if not compact_only and self.compact.fallback_fraction(self.window) > _COMPACT_MAX_FALLBACK:
                 # too many chunks would gather per pair (dense scans next to many fields): the standard kernel is faster
                 self.compact, self.window = None, 0
+        # passes of 1-4 fields stream the packed records (positions + weights, 5.33 bytes per pair) when the geometry's
+        # weights allow the lossless 26-bit code and the memory is there; identical bits either way
+        self.packed_stream = (packed and self.compact is not None and self.n_fields <= 4
+                              and self.compact.ensure_packed(self.csr))
 
     def _check_fields(self, fields, masks, shared_mask):
         torch = _native.torch_mod()
@@ -144,6 +148,14 @@ class CsrGridder:
         compact copy, ``rg_csr_apply_f32`` otherwise)."""
         csr = self.csr
         nz, ny, nx = self.grid_shape
+        if self.compact is not None and self.packed_stream and self.tile == 0:
+            c = self.compact
+            _native.check(self.lib.rg_csr_compact_apply_packed_f32(
+                _native.ptr(csr.indptr), int(csr.is_i64), _native.ptr(c.rec), _native.ptr(c.rec_ptr), c.w_base,
+                _native.ptr(c.dict_ptr), _native.ptr(c.dict), self.n_vox, csr.n_pairs, nx, ny, _native.ptr(self.packed),
+                self.n_fields, self.stride, self.n_gates, float(np.float32(fill_value)), _native.ptr(out), self.window,
+                _native.stream_ptr()), "rg_csr_compact_apply_packed_f32")
+            return
         if self.compact is not None:
             c = self.compact
             _native.check(self.lib.rg_csr_compact_apply_f32(
@@ -171,7 +183,11 @@ class CsrGridder:
             return None
         csr, c = self.csr, self.compact
         ip = 8 if csr.is_i64 else 4
-        return (6 * csr.n_pairs + 4 * c.n_dict + 8 * int(c.dict_ptr.numel()) + ip * (self.n_vox + 1)
+        if self.packed_stream:      # 16-byte records of three pairs + one record offset per segment
+            stream = 16 * int(c.rec.shape[0]) + 8 * int(c.rec_ptr.numel())
+        else:
+            stream = 6 * csr.n_pairs
+        return (stream + 4 * c.n_dict + 8 * int(c.dict_ptr.numel()) + ip * (self.n_vox + 1)
                 + self.n_fields * (5 * self.n_gates + 4 * self.n_vox))
 
 
