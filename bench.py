@@ -189,7 +189,10 @@ def cpu_baseline(pool, n_workers, geom, vol, field_name, n_vox_total, max_pairs)
         gidx = csr.gate_indices[p0:p1].cpu().numpy()
     else:                                          # compact-only geometry: rebuild the sample's index array
         gidx = geom.device_compact().decode(csr, v0, v1).cpu().numpy()
-    wts = csr.weights[p0:p1].cpu().numpy()
+    if csr.weights is not None:
+        wts = csr.weights[p0:p1].cpu().numpy()
+    else:                                          # packed-only geometry: unpack the sample's weights (lossless code)
+        wts = geom.device_compact().decode_weights(csr, v0, v1).cpu().numpy()
     shape = (1, r1 - r0, nx)
     data, mask = oracle.merge_masks(vol.fields[field_name])
     oracle.csr_apply(indptr[:2], gidx[:int(indptr[1])], wts[:int(indptr[1])], data, mask, (1, 1, 1))  # touch code paths
@@ -539,7 +542,9 @@ def run_rank(args):
         }
         try:        # what a pure streaming read gets on this box, same process, outside the timed region
             csr_now = gridder.csr if gridder is not None else None
+            comp_now = gridder.compact if gridder is not None else None
             ceiling = measured_read_ceiling(torch, rg, dev, [csr_now.weights if csr_now is not None else None,
+                                                             comp_now.rec if comp_now is not None else None,
                                                              search.sorted_gates if search is not None else None])
             if ceiling:
                 result["roofline"]["ceiling_measured"] = round(ceiling, 1)

@@ -164,13 +164,22 @@ class RoiSearch:
         return DeviceCSR(indptr, gate_idx, weights, max_gate)
 
 
-def _build_compact_only(search: "RoiSearch", weighting: str, pairs_per_slab: int = 1_200_000_000):
+_PACK_BASE_EXPONENT = {"barnes2": 121, "nearest": 127}   # smallest float32 exponent a weight can have (exp(-4)+1e-5 = 2^-6 * 1.17)
+
+
+def _build_compact_only(search: "RoiSearch", weighting: str, pairs_per_slab: int = 1_200_000_000, packed: bool = False):
     """Count -> scan -> per slab of whole grid levels: fill the slab's gate indices into a scratch buffer, derive the
     dictionaries and 16-bit positions of the slab's chunks (chunks never cross a level), drop the scratch.  The int32
     index array of the whole grid -- half of the standard CSR -- never exists, so a geometry of P pairs needs about
     6.2*P bytes instead of 8*P (+2.2*P for the copy).
-    Returns ``(DeviceCSR without gate_indices, CompactCSR)`` or ``None`` when a chunk holds more than 65536 distinct
-    gates."""
+
+    ``packed``: additionally fold every slab's positions and weights into the 16-byte records of
+    ``rg_csr_compact_pack`` (three pairs each) and keep ONLY those: 5.4*P bytes, and the kernel's fastest stream.  The
+    weight code is lossless for weights within 8 binades of the weighting's smallest possible value (Barnes, uniform);
+    should a weight fall outside (it cannot for those weightings), the pack kernel flags it and the caller falls back.
+
+    Returns ``(DeviceCSR without gate_indices [and without weights], CompactCSR)`` or ``None`` when a chunk holds more
+    than 65536 distinct gates in a single segment (or packing was asked for and is not possible)."""
     from .grid_geometry import CompactCSR
     torch = _native.torch_mod()
     lib = _native.load_library()
@@ -178,6 +187,8 @@ def _build_compact_only(search: "RoiSearch", weighting: str, pairs_per_slab: int
     n_xy = ny * nx
     n_vox = nz * n_xy
     dev = search.dev
+    if packed and weighting not in _PACK_BASE_EXPONENT:
+        return None
     with torch.cuda.device(dev):
         stream = _native.stream_ptr()
         counts = torch.zeros(n_vox + 1, dtype=torch.int32, device=dev)
@@ -193,8 +204,24 @@ def _build_compact_only(search: "RoiSearch", weighting: str, pairs_per_slab: int
         del counts, ws
         level_ptr = indptr[::n_xy].cpu().numpy()                 # pair offset at the start of every grid level
         n_pairs = int(level_ptr[-1])
-        weights = torch.empty(max(n_pairs, 1), dtype=torch.float32, device=dev)[:n_pairs]
-        local = torch.empty(max(n_pairs, 1), dtype=torch.int16, device=dev)[:n_pairs]
+        weights = local = rec = rec_ptr = None
+        w_base = 0
+        if packed:
+            starts = torch.tensor(CompactCSR.segment_starts(nx), device=dev, dtype=torch.int64)
+            line0 = torch.arange(nz * ny, device=dev, dtype=torch.int64) * nx
+            edges = indptr[(line0[:, None] + starts[None, :]).reshape(-1)].view(nz * ny, -1)
+            n_rec_seg = ((edges[:, 1:] - edges[:, :-1]) + 2) // 3
+            nsx = n_rec_seg.shape[1]
+            rec_ptr = torch.zeros(n_rec_seg.numel() + 1, dtype=torch.int64, device=dev)
+            rec_ptr[1:] = torch.cumsum(n_rec_seg.reshape(-1), 0)
+            n_rec = int(rec_ptr[-1])
+            rec = torch.empty((max(n_rec, 1), 4), dtype=torch.int32, device=dev)[:n_rec]
+            w_base = _PACK_BASE_EXPONENT[weighting] << 23
+            err = torch.zeros(1, dtype=torch.int32, device=dev)
+            del edges, n_rec_seg, line0
+        else:
+            weights = torch.empty(max(n_pairs, 1), dtype=torch.float32, device=dev)[:n_pairs]
+            local = torch.empty(max(n_pairs, 1), dtype=torch.int16, device=dev)[:n_pairs]
         count_parts, dict_parts = [], []
         max_gate = -1
         iz0 = 0
@@ -204,28 +231,46 @@ def _build_compact_only(search: "RoiSearch", weighting: str, pairs_per_slab: int
                 iz1 += 1
             p0, p1 = int(level_ptr[iz0]), int(level_ptr[iz1])
             scratch = torch.empty(max(p1 - p0, 1), dtype=torch.int32, device=dev)[:p1 - p0]
+            if packed:       # the slab's weights and positions are scratch too: only the records survive
+                w_slab = torch.empty(max(p1 - p0, 1), dtype=torch.float32, device=dev)[:p1 - p0]
+                l_slab = torch.empty(max(p1 - p0, 1), dtype=torch.int16, device=dev)[:p1 - p0]
+                w_ptr, l_ptr = _native.ptr(w_slab) - 4 * p0, _native.ptr(l_slab) - 2 * p0
+            else:
+                w_ptr, l_ptr = _native.ptr(weights), _native.ptr(local)
             if p1 > p0:
-                # the fill kernel writes at absolute pair positions: shift the index pointer so that the slab's first
-                # pair lands at the start of the scratch buffer; the weights go straight to their final place
+                # the fill kernel writes at absolute pair positions: shift the pointers so that the slab's first pair
+                # lands at the start of the scratch buffers (the weights go straight to their final place otherwise)
                 _native.check(lib.rg_geom_fill_f32(
                     _native.ptr(search.sorted_gates), _native.ptr(search.cell_start), search.cells, _native.ptr(search.xc),
                     _native.ptr(search.yc), _native.ptr(search.zc) + 4 * iz0, iz1 - iz0, ny, nx, search.min_radius,
                     search.beam_factor, _native.WEIGHTINGS[weighting], _native.ptr(indptr) + 8 * iz0 * n_xy,
-                    _native.ptr(scratch) - 4 * p0, _native.ptr(weights), stream), "rg_geom_fill_f32")
+                    _native.ptr(scratch) - 4 * p0, w_ptr, stream), "rg_geom_fill_f32")
                 max_gate = max(max_gate, int(scratch.max().item()))
             built = CompactCSR._planes(indptr[iz0 * n_xy:iz1 * n_xy + 1], _native.ptr(scratch) - 4 * p0, iz1 - iz0, ny, nx,
-                                       _native.ptr(local))
+                                       l_ptr)
             if built is None:
                 return None
             count_parts.append(built[0])
             dict_parts.append(built[1])
+            if packed and p1 > p0:
+                seg0 = iz0 * ny * nsx
+                _native.check(lib.rg_csr_compact_pack(
+                    _native.ptr(indptr) + 8 * iz0 * n_xy, 1, l_ptr, w_ptr, (iz1 - iz0) * n_xy, nx, ny,
+                    _native.ptr(rec_ptr) + 8 * seg0, w_base, _native.ptr(rec), _native.ptr(err), stream),
+                    "rg_csr_compact_pack")
+                if int(err.item()):
+                    logger.info("a weight does not fit the 26-bit code: keeping the plain compact layout instead")
+                    return None
+                del w_slab, l_slab
             del scratch
             iz0 = iz1
         counts_all = torch.cat(count_parts) if count_parts else torch.zeros(0, dtype=torch.int64, device=dev)
         compact = CompactCSR._finish(indptr, search.grid_shape, local, counts_all, dict_parts)
+        if packed:
+            compact.rec, compact.rec_ptr, compact.w_base = rec, rec_ptr, w_base
         if n_pairs <= _INT32_MAX:
             indptr = indptr.to(torch.int32)
-    return DeviceCSR(indptr, None, weights, max_gate), compact
+    return DeviceCSR(indptr, None, weights, max_gate, n_pairs=n_pairs), compact
 
 
 def compute_grid_geometry(
@@ -254,8 +299,10 @@ def compute_grid_geometry(
     ``layout`` (build-specific): ``"csr"`` keeps the reference's three arrays in HBM; ``"auto"`` does so whenever
     they and their compact copy fit the free memory, and otherwise falls to ``"compact"``, which keeps
     ``indptr``, ``weights`` and the compact copy of the gate indices only (``grid_geometry.CompactCSR``, 6.2 instead
-    of 8 bytes per pair) -- for geometries too large to hold both; ``.gate_indices`` is then rebuilt from the copy
-    when somebody asks for it.
+    of 8 bytes per pair), or to ``"packed"``, which keeps ``indptr`` and the packed pair stream only (positions and
+    losslessly coded weights of three pairs per 16-byte record: 5.4 bytes per pair; Barnes and uniform weights) -- for
+    geometries too large to hold both; ``.gate_indices`` / ``.weights`` are then rebuilt from the copy when somebody
+    asks for them.
 
     Reference quirks kept on purpose: ``radar_altitude`` is subtracted from ``gate_z``
     in float32 (compute.py:182), the returned geometry does not carry it (compute.py:277-284 => 0.0), and
@@ -273,16 +320,27 @@ def compute_grid_geometry(
     logger.info(f"TOA filter: {search.n_binned:,} of {search.n_gates:,} gates kept (below {toa}m and within reach "
                 f"of the grid); cell size {search.cell_size:.0f} m")
     logger.info(f"Processing {nz} z-levels on {search.dev}...")
-    if layout not in ("csr", "compact", "auto"):
-        raise ValueError("layout must be 'csr', 'compact' or 'auto'")
+    if layout not in ("csr", "compact", "packed", "auto"):
+        raise ValueError("layout must be 'csr', 'compact', 'packed' or 'auto'")
     if layout == "auto":
         # the reference's arrays whenever they AND their compact copy fit (8 + 2.2 bytes per pair: gridding then runs
         # through the copy and the int32 index array stays available), the compact layout alone (6.2 bytes per pair)
         # for geometries where they do not (config 4: 33 G pairs = 266 GB of standard CSR on a 288 GB device)
         n_pairs = search.count_pairs()
         free_b, _ = _native.torch_mod().cuda.mem_get_info(search.dev)
-        layout = "csr" if 10.4 * n_pairs + (10 << 30) <= free_b else "compact"
+        # ... (+5.4 bytes per pair for the packed stream when there is room for it as well)
+        layout = ("csr" if 10.4 * n_pairs + (10 << 30) <= free_b
+                  else "packed" if weighting in _PACK_BASE_EXPONENT else "compact")
         logger.info(f"{n_pairs:,} pairs, {free_b / 1e9:.0f} GB free -> layout '{layout}'")
+    if layout == "packed":
+        built = _build_compact_only(search, weighting, packed=True)
+        if built is not None:
+            csr, compact = built
+            logger.info(f"Geometry complete ({csr.n_pairs:,} total pairs, packed layout: {compact.rec.shape[0]:,} records, "
+                        f"{compact.n_dict:,} dictionary entries).")
+            return GridGeometry.from_device(grid_shape, grid_limits, csr, toa, compact=compact)
+        logger.info("packed layout not possible for this geometry; building the compact layout")
+        layout = "compact"
     if layout == "compact":
         built = _build_compact_only(search, weighting)
         if built is not None:

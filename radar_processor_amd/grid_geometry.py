@@ -28,12 +28,12 @@ class DeviceCSR:
 
     __slots__ = ("indptr", "gate_indices", "weights", "n_vox", "n_pairs", "max_gate", "is_i64")
 
-    def __init__(self, indptr, gate_indices, weights, max_gate: int):
+    def __init__(self, indptr, gate_indices, weights, max_gate: int, n_pairs: Optional[int] = None):
         self.indptr = indptr
         self.gate_indices = gate_indices   # None when the geometry was built compact-only (see CompactCSR)
-        self.weights = weights
+        self.weights = weights             # None when it was built packed-only (weights live in CompactCSR.rec)
         self.n_vox = int(indptr.shape[0]) - 1
-        self.n_pairs = int(weights.shape[0])
+        self.n_pairs = int(weights.shape[0]) if weights is not None else int(n_pairs)
         self.max_gate = int(max_gate)   # largest gate index referenced (-1 when there are no pairs)
         self.is_i64 = indptr.dtype == _native.torch_mod().int64
 
@@ -88,7 +88,7 @@ class CompactCSR:
         torch = _native.torch_mod()
         lib = _native.load_library()
         dev = csr.indptr.device
-        if csr.n_pairs == 0 or self.local_idx is None:
+        if csr.n_pairs == 0 or self.local_idx is None or csr.weights is None:
             return False
         free_b, _ = torch.cuda.mem_get_info(dev)
         if free_b < 5.6 * csr.n_pairs + (6 << 30):
@@ -267,7 +267,53 @@ class CompactCSR:
         return cls(local, dict_ptr, dict_, int(counts.max()) if n_chunks else 0, window_cap, grid_shape,
                    chunk_pairs, counts)
 
-    def decode(self, csr: "DeviceCSR", row0: int = 0, row1: Optional[int] = None, rows_per_slab: int = 2_000_000):
+    def _record_fields(self, csr: "DeviceCSR", r0: int, r1: int):
+        """Positions (int64) and weights (float32) of the pairs of rows ``[r0, r1)``, unpacked from the 16-byte records
+        (the inverse of ``rg_csr_compact_pack``; used when the plain ``local_idx`` / ``weights`` arrays do not exist)."""
+        torch = _native.torch_mod()
+        dev = csr.indptr.device
+        nz, ny, nx = self.grid_shape
+        nsx = (nx + 63) // 64
+        base, extra = divmod(nx, nsx)
+        ip = csr.indptr[r0:r1 + 1].to(torch.int64)
+        rows = torch.arange(r0, r1, device=dev, dtype=torch.int64)
+        line = rows // nx
+        x = rows - line * nx
+        split = extra * (base + 1)
+        sx = (x // (base + 1)).where(x < split, extra + (x - split) // max(base, 1))
+        seg = line * nsx + sx
+        x0 = (sx * base + torch.minimum(sx, torch.full_like(sx, extra)))
+        seg_first_pair = csr.indptr[line * nx + x0].to(torch.int64)            # pair offset where the row's segment starts
+        lens = ip[1:] - ip[:-1]
+        n = int(ip[-1] - ip[0])
+        row_of_pair = torch.repeat_interleave(torch.arange(r1 - r0, device=dev), lens, output_size=n)
+        pair = torch.arange(n, device=dev, dtype=torch.int64) + ip[0]
+        q = pair - seg_first_pair[row_of_pair]                                 # pair's offset inside its segment
+        rec = self.rec[self.rec_ptr[seg[row_of_pair]] + q // 3].to(torch.int64) & 0xFFFFFFFF      # [n, 4] as unsigned
+        j = q % 3
+        code = torch.where(j == 0, rec[:, 0], torch.where(j == 1, rec[:, 1], rec[:, 2])) & 0x3FFFFFF
+        weights = (code + self.w_base).to(torch.int32).view(torch.float32)
+        p2 = (rec[:, 0] >> 26) | ((rec[:, 1] >> 26) << 6) | (((rec[:, 2] >> 26) & 0xF) << 12)
+        pos = torch.where(j == 0, rec[:, 3] & 0xFFFF, torch.where(j == 1, rec[:, 3] >> 16, p2))
+        return pos, weights
+
+    def decode_weights(self, csr: "DeviceCSR", row0: int = 0, row1: Optional[int] = None, rows_per_slab: int = 500_000):
+        """float32 weights of rows ``[row0, row1)``: a view of ``csr.weights`` when it exists, else unpacked from the
+        records (bit-exact: the 26-bit code is lossless)."""
+        torch = _native.torch_mod()
+        row1 = csr.n_vox if row1 is None else row1
+        q0, q1 = int(csr.indptr[row0]), int(csr.indptr[row1])
+        if csr.weights is not None:
+            return csr.weights[q0:q1]
+        out = torch.empty(max(q1 - q0, 1), dtype=torch.float32, device=csr.indptr.device)[:q1 - q0]
+        for r0 in range(row0, row1, rows_per_slab):
+            r1 = min(row1, r0 + rows_per_slab)
+            p0, p1 = int(csr.indptr[r0]), int(csr.indptr[r1])
+            if p1 > p0:
+                out[p0 - q0:p1 - q0] = self._record_fields(csr, r0, r1)[1]
+        return out
+
+    def decode(self, csr: "DeviceCSR", row0: int = 0, row1: Optional[int] = None, rows_per_slab: int = 500_000):
         """The standard int32 gate indices of rows ``[row0, row1)`` (default: all), rebuilt from positions and
         dictionaries; device tensor of ``indptr[row1] - indptr[row0]`` entries."""
         torch = _native.torch_mod()
@@ -291,7 +337,10 @@ class CompactCSR:
                 header = self.dict[(start_of_row + wave).clamp(max=self.n_dict - 1)].to(torch.int64)
                 start_of_row = start_of_row + torch.where(is_split, header, torch.zeros_like(header))
             start_of_pair = torch.repeat_interleave(start_of_row, ip[1:] - ip[:-1], output_size=p1 - p0)
-            pos = self.local_idx[p0:p1].to(torch.int64) & 0xFFFF
+            if self.local_idx is not None:
+                pos = self.local_idx[p0:p1].to(torch.int64) & 0xFFFF
+            else:
+                pos = self._record_fields(csr, r0, r1)[0]
             out[p0 - q0:p1 - q0] = self.dict[start_of_pair + pos]
         return out
 
@@ -335,8 +384,9 @@ class GridGeometry:
                 raise AttributeError(f"GridGeometry has no {name}")
             logger.debug("copying %s to the host", name)
             dev_arr = getattr(self._dev, name)
-            if dev_arr is None:      # compact-only geometry: rebuild the reference's index array from the copy
-                dev_arr = self._compact[1].decode(self._dev)
+            if dev_arr is None:      # compact-only / packed-only geometry: rebuild the reference's array from the copy
+                dev_arr = (self._compact[1].decode(self._dev) if name == "gate_indices"
+                           else self._compact[1].decode_weights(self._dev))
             arr = dev_arr.cpu().numpy()
             setattr(self, "_" + name, arr)
         return arr
@@ -394,7 +444,10 @@ class GridGeometry:
     # ---- reference helper methods (geometry.py:54-91) --------------------------------------------
     def memory_usage_mb(self) -> float:
         if self._indptr is None and self._dev is not None:
-            return self._dev.nbytes() / 1e6
+            cached = getattr(self, "_compact", None)      # a compact-only / packed-only geometry lives in its copy
+            extra = cached[1].nbytes() if (cached is not None and cached[1] is not None
+                                           and (self._dev.gate_indices is None or self._dev.weights is None)) else 0
+            return (self._dev.nbytes() + extra) / 1e6
         return (self.indptr.nbytes + self.gate_indices.nbytes + self.weights.nbytes) / 1e6
 
     def n_grid_points(self) -> int:
@@ -462,7 +515,7 @@ class GridGeometry:
         torch = _native.torch_mod()
         if self._dev is not None:   # resident on another GPU: replicate device-to-device
             src = self._dev
-            if src.gate_indices is None:
+            if src.gate_indices is None or src.weights is None:
                 raise _native.NativeError("a compact-only geometry cannot be replicated to another GPU; rebuild it there")
             self._dev = DeviceCSR(src.indptr.to(dev), src.gate_indices.to(dev), src.weights.to(dev), src.max_gate)
             return self._dev

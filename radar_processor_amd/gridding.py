@@ -94,6 +94,10 @@ class CsrGridder:
             raise IndexError(f"index {self.csr.max_gate} is out of bounds for axis 0 with size {self.n_gates}")
         self.packed = torch.empty(max(self.n_gates, 1) * self.stride, dtype=torch.float32, device=self.dev)
         compact_only = self.csr.gate_indices is None
+        packed_only = self.csr.weights is None           # only the packed pair stream exists (layout="packed")
+        if packed_only and self.n_fields > 4:
+            raise _native.NativeError("this geometry holds only the packed pair stream, which serves passes of 1-4 fields; "
+                                      "grid larger groups in several passes (grid_fields_device does)")
         # Measured (config 2 / bench grid, ms per pass, standard vs compact kernel): 1 field 1.81 / 1.28 and 13.1 / 9.3,
         # 2 fields 2.1 / 1.76 and 15.2 / 13.3, 3 fields 2.37 / 2.68 and 16.9 / 15.1, 4 fields 2.86 / 3.4 and 19.8 / 19.3,
         # 8 fields 7.3 / 9.6 and 49.8 / 65.  What decides is the LDS window the compact kernel needs next to its tiles:
@@ -114,7 +118,7 @@ class CsrGridder:
                 self.compact, self.window = None, 0
         # passes of 1-4 fields stream the packed records (positions + weights, 5.33 bytes per pair) when the geometry's
         # weights allow the lossless 26-bit code and the memory is there; identical bits either way
-        self.packed_stream = (packed and self.compact is not None and self.n_fields <= 4
+        self.packed_stream = ((packed or packed_only) and self.compact is not None and self.n_fields <= 4
                               and self.compact.ensure_packed(self.csr))
 
     def _check_fields(self, fields, masks, shared_mask):
@@ -148,7 +152,7 @@ class CsrGridder:
         compact copy, ``rg_csr_apply_f32`` otherwise)."""
         csr = self.csr
         nz, ny, nx = self.grid_shape
-        if self.compact is not None and self.packed_stream and self.tile == 0:
+        if self.compact is not None and self.packed_stream and (self.tile == 0 or csr.weights is None):
             c = self.compact
             _native.check(self.lib.rg_csr_compact_apply_packed_f32(
                 _native.ptr(csr.indptr), int(csr.is_i64), _native.ptr(c.rec), _native.ptr(c.rec_ptr), c.w_base,
@@ -259,9 +263,10 @@ def grid_fields_device(geometry: GridGeometry, fields: Sequence, masks: Optional
     elif not (out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and out.numel() == n_fields * n_vox):
         raise ValueError("out must be a contiguous cuda float32 tensor of shape [F, nz, ny, nx]")
     n_gates = int(fields[0].numel())
+    per_pass = 4 if geometry.device_csr(dev).weights is None else _native.RG_MAX_FIELDS   # packed-only: 1-4 per pass
     with torch.cuda.device(dev):
-        for f0 in range(0, n_fields, _native.RG_MAX_FIELDS):
-            f1 = min(n_fields, f0 + _native.RG_MAX_FIELDS)
+        for f0 in range(0, n_fields, per_pass):
+            f1 = min(n_fields, f0 + per_pass)
             gridder = _cached_gridder(geometry, n_gates, f1 - f0, dev,
                                       compact=_use_compact(geometry, dev))
             gridder.pack(fields[f0:f1], masks[f0:f1], shared_mask)

@@ -303,6 +303,42 @@ def test_c2_compact_only_layout(c2, tmp_path):
                                  str(tmp_path), layout="coo")
 
 
+def test_c2_packed_only_layout(c2, tmp_path):
+    """compute_grid_geometry(layout="packed"): only the row pointers, the dictionaries and the packed pair stream exist
+    (positions + losslessly coded weights, three pairs per 16-byte record).  The decoded indices AND weights equal the
+    standard build bit for bit, 1-4 fused fields grid to the same bits as the standard kernel, larger groups are split,
+    and a weighting whose weights do not fit the 26-bit code (Cressman) falls back to the compact layout."""
+    rg, torch, dev, vol, cfg = c2["rg"], c2["torch"], c2["dev"], c2["vol"], c2["cfg"]
+    std = c2["geom"].device_csr(dev)
+    geom = rg.compute_grid_geometry(vol.gate_x, vol.gate_y, vol.gate_z, cfg["grid_shape"], cfg["grid_limits"],
+                                    str(tmp_path), layout="packed")
+    csr = geom.device_csr(dev)
+    assert csr.gate_indices is None and csr.weights is None and csr.n_pairs == std.n_pairs and csr.max_gate == std.max_gate
+    assert torch.equal(csr.indptr.to(torch.int64), std.indptr.to(torch.int64))
+    compact = geom.device_compact(dev)
+    assert compact.local_idx is None and compact.rec is not None
+    assert compact.rec.shape[0] * 16 < 5.45 * csr.n_pairs
+    nx = cfg["grid_shape"][2]
+    for r0, r1 in ((0, 40 * nx), (7 * nx + 13, 1234 * nx + 5), (csr.n_vox - 999, csr.n_vox)):
+        q0, q1 = int(std.indptr[r0]), int(std.indptr[r1])
+        assert torch.equal(compact.decode(csr, r0, r1), std.gate_indices[q0:q1])
+        assert torch.equal(compact.decode_weights(csr, r0, r1).view(torch.int32), std.weights[q0:q1].view(torch.int32))
+    names = ["DBZH", "ZDR", "RHOHV"]
+    f = [c2["fields"][n] for n in names]
+    m = [c2["masks"][n] for n in names]
+    for nf in (1, 2, 3):
+        want = rg.grid_fields_device(c2["geom"], f[:nf], m[:nf])
+        got = rg.grid_fields_device(geom, f[:nf], m[:nf])
+        assert torch.equal(got.view(torch.int32), want.view(torch.int32)), nf
+    five = rg.grid_fields_device(geom, f + f[:2], m + m[:2])                # 5 fields: a pass of 4 and a pass of 1
+    assert torch.equal(five[4].view(torch.int32), rg.grid_fields_device(c2["geom"], f[1:2], m[1:2])[0].view(torch.int32))
+    assert geom.n_pairs() == std.n_pairs and geom.memory_usage_mb() < 0.75 * c2["geom"].memory_usage_mb()
+    cress = rg.compute_grid_geometry(vol.gate_x, vol.gate_y, vol.gate_z, (2, 64, 64),
+                                     ((1000.0, 2000.0), (-20e3, 20e3), (-20e3, 20e3)), str(tmp_path),
+                                     weighting="cressman", layout="packed")
+    assert cress.device_csr(dev).weights is not None and cress.device_csr(dev).gate_indices is None
+
+
 def test_c2_pipeline_graph_with_compact_copy(c2):
     """VolumePipeline(compact=True): the captured hipGraph (pack -> rg_csr_compact_apply_f32 -> COLMAX/argmax -> CAPPI)
     replays to the same bits as the standard pipeline."""
@@ -432,6 +468,29 @@ def test_metric_compact_only_layout_with_int64_offsets(metric, tmp_path):
     for r0, r1 in (((21 * ny + 7) * nx + 3, (21 * ny + 12) * nx + 1999), ((39 * ny + 1990) * nx, csr.n_vox), (0, 3 * nx)):
         p0, p1 = int(std.indptr[r0]), int(std.indptr[r1])
         assert torch.equal(compact.decode(csr, r0, r1), std.gate_indices[p0:p1])
+    got = rg.grid_fields_device(geom, [metric["f"]], [metric["m"]])
+    assert torch.equal(got.view(-1).view(torch.int32), k1.view(-1).view(torch.int32))
+    del got, geom, compact, csr
+    torch.cuda.empty_cache()
+
+
+def test_metric_packed_only_layout_with_int64_offsets(metric, tmp_path):
+    """layout="packed" on the metric workload: records packed slab by slab through shifted 64-bit pointers; decoded
+    indices and weights beyond pair offset 2^31 equal the standard build, the grid equals K1's bit for bit."""
+    rg, torch, dev, vol, cfg = metric["rg"], metric["torch"], metric["dev"], metric["vol"], metric["cfg"]
+    std = metric["geom"].device_csr(dev)
+    k1, _ = _metric_grids(metric)
+    geom = rg.compute_grid_geometry(vol.gate_x, vol.gate_y, vol.gate_z, cfg["grid_shape"], cfg["grid_limits"],
+                                    str(tmp_path), layout="packed")
+    csr = geom.device_csr(dev)
+    assert csr.gate_indices is None and csr.weights is None and csr.is_i64 and csr.n_pairs == std.n_pairs
+    assert torch.equal(csr.indptr, std.indptr)
+    compact = geom.device_compact(dev)
+    nz, ny, nx = cfg["grid_shape"]
+    for r0, r1 in (((21 * ny + 7) * nx + 3, (21 * ny + 12) * nx + 1999), ((39 * ny + 1990) * nx, csr.n_vox), (0, 3 * nx)):
+        p0, p1 = int(std.indptr[r0]), int(std.indptr[r1])
+        assert torch.equal(compact.decode(csr, r0, r1), std.gate_indices[p0:p1])
+        assert torch.equal(compact.decode_weights(csr, r0, r1).view(torch.int32), std.weights[p0:p1].view(torch.int32))
     got = rg.grid_fields_device(geom, [metric["f"]], [metric["m"]])
     assert torch.equal(got.view(-1).view(torch.int32), k1.view(-1).view(torch.int32))
     del got, geom, compact, csr
