@@ -538,6 +538,10 @@ def run_rank(args):
                 # `achieved` when the compact device copy is in use, because that kernel moves fewer bytes per pair
                 "reference_format_bytes_per_launch": int(ref_format_bytes),
                 "reference_format_GBps": round(ref_format_bytes / (kernel_ms * 1e-3) / 1e9, 1),
+                "reference_format_frac": round(ref_format_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "bytes_note": ("achieved/frac count the bytes THIS kernel has to move (its own compact format); the "
+                               "reference_format_* figures price the same launch in SURVEY 8(d)'s 8-bytes-per-pair CSR and "
+                               "can exceed the HBM peak: they measure throughput, not bandwidth"),
             },
         }
         try:        # what a pure streaming read gets on this box, same process, outside the timed region
