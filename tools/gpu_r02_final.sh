@@ -25,3 +25,5 @@ PY
 timeout -k 10 240 bash tools/profile_bench.sh r02_metric > gpurun_out/r02z_p1.log 2>&1; tail -1 gpurun_out/r02z_p1.log
 timeout -k 10 200 bash tools/profile_bench.sh r02_c3 --config C2 --fields 3 > gpurun_out/r02z_p4.log 2>&1; tail -1 gpurun_out/r02z_p4.log
 timeout -k 10 240 bash tools/profile_bench.sh r02_metric_f3 --fields 3 > gpurun_out/r02z_p6.log 2>&1; tail -1 gpurun_out/r02z_p6.log
+timeout -k 10 200 bash tools/profile_bench.sh r02_c2 --config C2 > gpurun_out/r02z_p3.log 2>&1; tail -1 gpurun_out/r02z_p3.log
+timeout -k 10 300 bash tools/profile_bench.sh r02_c4 --config C4 > gpurun_out/r02z_p5.log 2>&1; tail -1 gpurun_out/r02z_p5.log
