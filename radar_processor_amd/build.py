@@ -58,7 +58,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
                os.path.join(INCLUDE, "radargrid_hip.h")]
     common = ["-std=c++17", "-O3", f"--offload-arch={ARCH}", "-fPIC",
               f"-I{INCLUDE}", f"-I{CSRC}", "-Wall", "-Wno-unused-result", *COMMON_FLAGS]
-    objs = []
+    objs, jobs = [], []
     for src, extra in SOURCES:
         src_path = os.path.join(CSRC, src)
         if not os.path.exists(src_path):
@@ -66,10 +66,16 @@ def build(force: bool = False, verbose: bool = True) -> str:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src_path] + headers):
-            cmd = [hipcc, *common, *extra, "-c", src_path, "-o", obj]
+            jobs.append([hipcc, *common, *extra, "-c", src_path, "-o", obj])
+    if jobs:      # the translation units are independent: compile them side by side (hipcc is a separate process each)
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print("[build]", " ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)
+        with ThreadPoolExecutor(max_workers=min(len(jobs), max(1, (os.cpu_count() or 2) // 2))) as pool:
+            list(pool.map(run, jobs))
     if force or _stale(LIB_PATH, objs):
         cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB_PATH]
         if verbose:
