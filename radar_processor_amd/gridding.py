@@ -98,12 +98,12 @@ class CsrGridder:
         if packed_only and self.n_fields > 4:
             raise _native.NativeError("this geometry holds only the packed pair stream, which serves passes of 1-4 fields; "
                                       "grid larger groups in several passes (grid_fields_device does)")
-        # Measured (config 2 / bench grid, ms per pass, standard vs compact kernel): 1 field 1.81 / 1.28 and 13.1 / 9.3,
-        # 2 fields 2.1 / 1.76 and 15.2 / 13.3, 3 fields 2.37 / 2.68 and 16.9 / 15.1, 4 fields 2.86 / 3.4 and 19.8 / 19.3,
+        # Measured (config 2 / bench grid, ms per pass, standard vs compact kernel): 1 field 1.9 / 1.11 and 13.1 / 8.4,
+        # 2 fields 2.1 / 1.69 and 14.7 / 11.6, 3 fields 2.32 / 2.21 and 16.5 / 14.6, 4 fields 3.0 / 3.3 and 20.5 / 19.5,
         # 8 fields 7.3 / 9.6 and 49.8 / 65.  What decides is the LDS window the compact kernel needs next to its tiles:
-        # up to about 16 KiB (bench grid: 768 entries x 16 bytes; config 2: 1792 x 8) it keeps enough workgroups per
-        # CU to win, beyond that (config 2 with 16-byte entries: 28 KiB; any 8-field pass) the standard kernel -- no
-        # window -- does.  A compact-only geometry has no choice.
+        # up to about 24 KiB (bench grid: 768 entries x 16 bytes; config 2 with three fields: 1792 x 12) it keeps enough
+        # workgroups per CU to win, beyond that (config 2 with four fields: 28 KiB; any 8-field pass) the standard kernel
+        # -- no window -- does.  A compact-only geometry has no choice.
         want = compact or compact_only
         self.compact = geometry.device_compact(self.dev) if (want and self.csr.n_pairs) else None
         if (self.compact is not None and not compact_only
@@ -196,7 +196,7 @@ class CsrGridder:
 
 
 _COMPACT_MIN_PAIRS = 50_000_000     # below this a pass takes well under a millisecond either way
-_COMPACT_MAX_WINDOW_BYTES = 16384  # LDS window beyond which the standard kernel is the faster one (CsrGridder.__init__)
+_COMPACT_MAX_WINDOW_BYTES = 24576  # LDS window beyond which the standard kernel is the faster one (CsrGridder.__init__)
 _COMPACT_MAX_FALLBACK = 0.02        # share of pairs allowed on the per-pair path before the standard kernel is preferred
 
 

@@ -235,10 +235,9 @@ def test_c2_compact_csr_is_bit_identical(c2):
     qc = rg.device_gate_mask(c2["fields"]["RHOHV"], "below", 0.8)
     m_c = CsrGridder(geom, f.numel(), 3, device=dev, compact=True)
     m_s = CsrGridder(geom, f.numel(), 3, device=dev)
-    assert m_c.compact is None and m_s.compact is None      # policy: 3 fused fields run the standard kernel (faster) ...
-    m_c.compact, m_c.window = c, c.window_for(3)            # ... but the compact kernel must give the same bits
-    two = CsrGridder(geom, f.numel(), 2, device=dev, compact=True)
-    assert two.compact is c                                 # 1-2 fields do go through the copy
+    assert m_c.compact is c and m_c.packed_stream and m_s.compact is None   # 3 fields: 21 KiB of window, packed stream
+    four = CsrGridder(geom, f.numel(), 4, device=dev, compact=True)
+    assert four.compact is None                            # policy: 4 fused fields (28 KiB window) run the standard kernel
     for gr in (m_c, m_s):
         gr.pack([c2["fields"][n] for n in names], [c2["masks"][n] for n in names], qc)
     want3 = torch.empty((3, m_s.n_vox), dtype=torch.float32, device=dev)
