@@ -336,7 +336,8 @@ int rg_csr_compact_apply_f32(const void* indptr, int32_t indptr_is_i64, const ui
  * Segments (the <= 64 rows one wavefront owns) are numbered line-major, seg = line * ceil(line_len / 64) + sx; segment
  * seg owns records rec_ptr[seg] .. rec_ptr[seg+1], ceil(pairs / 3) of them (rec_ptr has segments + 1 entries, built by the
  * caller).  rg_csr_compact_pack fills `records` from local_idx + weights; rg_csr_compact_apply_packed_f32 grids 1-4 fused
- * fields through them: the results of rg_csr_compact_apply_f32 / rg_csr_apply_f32 for the same fields, bit for bit. */
+ * fields through them: the results of rg_csr_compact_apply_f32 / rg_csr_apply_f32 for the same fields, bit for bit
+ * (tile: 0 = 384 pairs, the tile of the other two kernels; 576 / 768 are single-field tuning variants). */
 int rg_csr_compact_pack(const void* indptr, int32_t indptr_is_i64, const uint16_t* local_idx, const float* weights,
                         int64_t n_rows, int64_t line_len, int64_t lines_per_plane, const int64_t* rec_ptr,
                         uint32_t w_base, void* records, int32_t* error_flag, rg_stream_t stream);
@@ -344,7 +345,7 @@ int rg_csr_compact_apply_packed_f32(const void* indptr, int32_t indptr_is_i64, c
                                     const int64_t* rec_ptr, uint32_t w_base, const int64_t* dict_ptr,
                                     const int32_t* dict, int64_t n_vox, int64_t n_pairs, int64_t line_len,
                                     int64_t lines_per_plane, const float* packed, int32_t n_fields, int32_t stride,
-                                    int64_t n_gates, float fill_value, float* out, int32_t window_cap,
+                                    int64_t n_gates, float fill_value, float* out, int32_t window_cap, int32_t tile,
                                     rg_stream_t stream);
 
 /* number of chunks of a grid of n_rows rows (negative rg_status when the sizes do not factor) */

@@ -552,7 +552,9 @@ extern "C" int rg_csr_compact_apply_packed_f32(const void* indptr, int32_t indpt
                                                const int32_t* dict, int64_t n_vox, int64_t n_pairs, int64_t line_len,
                                                int64_t lines_per_plane, const float* packed, int32_t n_fields,
                                                int32_t stride, int64_t n_gates, float fill_value, float* out,
-                                               int32_t window_cap, rg_stream_t stream) {
+                                               int32_t window_cap, int32_t tile, rg_stream_t stream) {
+  RG_REQUIRE(tile == 0 || tile == 384 || ((tile == 576 || tile == 768) && n_fields == 1), RG_EINVAL,
+             "rg_csr_compact_apply_packed_f32: tile must be 0 / 384 (or, one field only, 576 / 768)");
   RG_REQUIRE(n_fields >= 1 && n_fields <= 4, RG_EUNSUPPORTED,
              "rg_csr_compact_apply_packed_f32: n_fields=%d not in 1..4 (5-8 fields use 128-pair tiles, not a whole number "
              "of 64-record loads)", n_fields);
@@ -581,6 +583,11 @@ extern "C" int rg_csr_compact_apply_packed_f32(const void* indptr, int32_t indpt
 #define RG_K1P(IND_, NF_)                                                                                              \
   launch_nf<IND_, NF_, 384, 0, 0, true>(window_cap, indptr, nullptr, nullptr, dict_ptr, dict, cg, n_vox, packed, n_gates, \
                                         fill_value, out, s, ps)
+#define RG_K1PT(IND_, TILE_)                                                                                            \
+  launch_nf<IND_, 1, TILE_, 0, 0, true>(window_cap, indptr, nullptr, nullptr, dict_ptr, dict, cg, n_vox, packed, n_gates, \
+                                        fill_value, out, s, ps)
+  if (tile == 576) return indptr_is_i64 ? RG_K1PT(int64_t, 576) : RG_K1PT(int32_t, 576);
+  if (tile == 768) return indptr_is_i64 ? RG_K1PT(int64_t, 768) : RG_K1PT(int32_t, 768);
   if (indptr_is_i64) {
     switch (n_fields) {
       case 1: return RG_K1P(int64_t, 1);
@@ -596,6 +603,7 @@ extern "C" int rg_csr_compact_apply_packed_f32(const void* indptr, int32_t indpt
     default: return RG_K1P(int32_t, 4);
   }
 #undef RG_K1P
+#undef RG_K1PT
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -152,13 +152,13 @@ class CsrGridder:
         compact copy, ``rg_csr_apply_f32`` otherwise)."""
         csr = self.csr
         nz, ny, nx = self.grid_shape
-        if self.compact is not None and self.packed_stream and (self.tile == 0 or csr.weights is None):
+        if self.compact is not None and self.packed_stream and (self.tile in (0, 576, 768) or csr.weights is None):
             c = self.compact
             _native.check(self.lib.rg_csr_compact_apply_packed_f32(
                 _native.ptr(csr.indptr), int(csr.is_i64), _native.ptr(c.rec), _native.ptr(c.rec_ptr), c.w_base,
                 _native.ptr(c.dict_ptr), _native.ptr(c.dict), self.n_vox, csr.n_pairs, nx, ny, _native.ptr(self.packed),
                 self.n_fields, self.stride, self.n_gates, float(np.float32(fill_value)), _native.ptr(out), self.window,
-                _native.stream_ptr()), "rg_csr_compact_apply_packed_f32")
+                self.tile if self.tile in (576, 768) else 0, _native.stream_ptr()), "rg_csr_compact_apply_packed_f32")
             return
         if self.compact is not None:
             c = self.compact

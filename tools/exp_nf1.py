@@ -19,12 +19,12 @@ g.pack([f], [m])
 print('packed stream:', g.packed_stream, 'bytes/launch', g.compact_bytes())
 print('window', g.window, 'dict B/pair', 4 * g.compact.n_dict / g.csr.n_pairs, 'max_dict', g.compact.max_dict)
 out = torch.empty((1, g.n_vox), dtype=torch.float32, device=dev)
-variants = [(0, 0), (384, 5), (903, 5)]   # (0, 0) = what ships: the packed stream if the weights are codable   # 90x = timing-only ablations (no row phase / no products / no window)
+variants = [(0, 0), (576, 0), (768, 0), (384, 5)]   # (0, 0) = what ships: the packed stream; 576/768 = packed, larger tiles   # 90x = timing-only ablations (no row phase / no products / no window)
 times = {v: [] for v in variants}
 for rnd in range(6):
     for t, r in variants:
         g.tile = 1000 * r + t
-        if (t, r) == (0, 0): g.tile = 0
+        if r == 0: g.tile = t
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); g.apply(out); e1.record(); e1.synchronize()
         if rnd:
