@@ -358,3 +358,75 @@ def test_compact_csr_rich_chunks(rg):
     ip3 = torch.arange(0, 64 * 1100 + 1, 1100, device=dev, dtype=torch.int64)
     csr3 = DeviceCSR(ip3.to(torch.int32), big, torch.ones(big.numel(), device=dev), int(big.max()))
     assert CompactCSR.build(csr3, (1, 1, 64)) is None
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_compact_and_packed_kernels_fuzz(rg, seed):
+    """Random hand-made CSRs -- random grid shapes (lines that are not multiples of 64 rows, planes that are not
+    multiples of 4 lines), empty rows, rows longer than a tile, few or many distinct gates per chunk, int32 / int64 row
+    pointers, 1-4 fused fields -- through the plain compact kernel, the packed stream and the packed-only decode, all
+    bit for bit against the standard kernel / the original arrays."""
+    import torch
+    from radar_processor_amd.gridding import CsrGridder
+    from radar_processor_amd.grid_geometry import CompactCSR, DeviceCSR, GridGeometry
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(1000 + seed)
+    nz, ny, nx = int(rng.integers(1, 4)), int(rng.integers(1, 11)), int(rng.integers(1, 400))
+    n_vox = nz * ny * nx
+    n_gates = int(rng.integers(50, 200_000))
+    lengths = rng.integers(0, int(rng.choice([3, 40, 130])), size=n_vox)
+    lengths[rng.random(n_vox) < rng.choice([0.0, 0.3, 0.9])] = 0
+    for r in rng.integers(0, n_vox, size=3):
+        lengths[r] = int(rng.integers(400, 1500))                      # rows longer than a tile
+    indptr = np.zeros(n_vox + 1, dtype=np.int64)
+    np.cumsum(lengths, out=indptr[1:])
+    n_pairs = int(indptr[-1])
+    if n_pairs == 0:
+        pytest.skip("empty case")
+    spread = int(rng.choice([30, 2000, n_gates]))                      # gate locality: tiny or huge dictionaries
+    base = rng.integers(0, n_gates, size=n_vox)
+    row_of_pair = np.repeat(np.arange(n_vox), lengths)
+    gidx = ((base[row_of_pair] + rng.integers(0, spread, size=n_pairs)) % n_gates).astype(np.int32)
+    wts = np.exp(-4.0 * rng.random(n_pairs)).astype(np.float32) + np.float32(1e-5)      # Barnes range: codable
+    as_i64 = bool(seed % 2)
+    ip_t = torch.from_numpy(indptr if as_i64 else indptr.astype(np.int32)).to(dev)
+    csr = DeviceCSR(ip_t, torch.from_numpy(gidx).to(dev), torch.from_numpy(wts).to(dev), int(gidx.max()))
+    shape, limits = (nz, ny, nx), ((0.0, 1.0), (0.0, 1.0), (0.0, 1.0))
+    geom = GridGeometry.from_device(shape, limits, csr, 17000.0)
+    compact = geom.device_compact(dev)
+    assert compact is not None and torch.equal(compact.decode(csr), csr.gate_indices)
+    assert compact.ensure_packed(csr)
+    # the records decode to the positions and the weights they were packed from
+    pos, w_back = compact._record_fields(csr, 0, n_vox)
+    assert torch.equal(pos, compact.local_idx.to(torch.int64) & 0xFFFF)
+    assert torch.equal(w_back.view(torch.int32), csr.weights.view(torch.int32))
+    fields = [torch.from_numpy(rng.normal(10, 20, n_gates).astype(np.float32)).to(dev) for _ in range(4)]
+    masks = [torch.from_numpy((rng.random(n_gates) < 0.2).astype(np.uint8)).to(dev) if k % 2 == 0 else None for k in range(4)]
+    fields[1][::7] = float("nan")                                      # unmasked NaN propagates like in NumPy
+    for nf in (1, 2, 3, 4):
+        g_s = CsrGridder(geom, n_gates, nf, device=dev)
+        g_p = CsrGridder(geom, n_gates, nf, device=dev)
+        g_p.compact, g_p.window, g_p.packed_stream = compact, compact.window_for(nf), True
+        g_c = CsrGridder(geom, n_gates, nf, device=dev)
+        g_c.compact, g_c.window, g_c.packed_stream = compact, compact.window_for(nf), False
+        want = torch.empty((nf, n_vox), dtype=torch.float32, device=dev)
+        for gr in (g_s, g_p, g_c):
+            gr.pack(fields[:nf], masks[:nf])
+        g_s.apply(want, fill_value=-3.0)
+        for name, gr in (("packed", g_p), ("compact", g_c)):
+            got = torch.full_like(want, 9.0)
+            gr.apply(got, fill_value=-3.0)
+            assert torch.equal(got.view(torch.int32), want.view(torch.int32)), (name, nf, shape)
+        # window too small for most chunks: the per-pair path of the packed kernel
+        g_p.window = 0
+        got = torch.full_like(want, 9.0)
+        g_p.apply(got, fill_value=-3.0)
+        assert torch.equal(got.view(torch.int32), want.view(torch.int32)), ("packed, no window", nf, shape)
+    # and against the float64 oracle (tolerance: float32 accumulation)
+    data = fields[0].cpu().numpy()
+    want64 = oracle.csr_apply_f64(indptr, gidx, wts, data, masks[0].cpu().numpy().astype(bool), shape, fill_value=-3.0)
+    g1 = CsrGridder(geom, n_gates, 1, device=dev, compact=True)
+    g1.pack(fields[:1], masks[:1])
+    out1 = torch.empty((1, n_vox), dtype=torch.float32, device=dev)
+    g1.apply(out1, fill_value=-3.0)
+    np.testing.assert_allclose(out1.cpu().numpy().reshape(shape), want64, rtol=2e-6, atol=2e-6 * 100.0)
