@@ -66,6 +66,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-compact", action="store_true",
                     help="csr mode: run the standard 8-byte-per-pair kernel instead of the compact device copy of the "
                          "CSR (identical results)")
+    ap.add_argument("--tile-kernel", action="store_true",
+                    help="csr mode, A/B: run the tile kernel over the packed records (bit-identical to the standard kernel) "
+                         "instead of the row-wise kernel")
     ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"),
                     help="process-group backend for N>1 (nccl = RCCL; gloo only for rehearsing ranks on one GPU)")
     ap.add_argument("--share-device", action="store_true",
@@ -394,8 +397,11 @@ def run_rank(args):
         n_pairs = gridder.csr.n_pairs
         ref_format_bytes = gridder.algorithmic_bytes()          # 8 bytes per pair
         if gridder.compact is not None:
-            algo_bytes = gridder.compact_bytes()                # what this kernel has to move: ~6.3 bytes per pair
-            kernel_name = "csr_compact_kernel"
+            algo_bytes = gridder.compact_bytes()                # what this kernel has to move: ~5.7 bytes per pair
+            if gridder.packed_stream and args.tile_kernel:
+                gridder.tile = 384                              # A/B: the tile kernel over the same packed records
+            kernel_name = ("csr_compact_rowwise_kernel" if gridder.packed_stream and gridder.tile == 0
+                           else "csr_compact_kernel")
         else:
             algo_bytes = ref_format_bytes
             kernel_name = "csr_apply_dyn_kernel"
@@ -470,8 +476,9 @@ def run_rank(args):
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else float("nan")
 
     # ---- the grid that was just timed is checked, outside the timed region (rank 0) ------------------------------
-    # the compact kernel against the reference-format kernel on the same inputs: every voxel, bit for bit; and the
-    # filled / empty pattern against the row pointers.  (Full parity against the oracle: tests/test_gpu_fullsize.py.)
+    # the compact kernel against the reference-format kernel on the same inputs, every voxel: the row-wise kernel to
+    # north_star's float32 tolerance (it sums in another order), the tile kernel over the same records bit for bit; and
+    # the filled / empty pattern against the row pointers.  (Parity against the oracle: tests/test_gpu_fullsize.py.)
     checked = None
     if rank == 0 and not c5 and args.mode == "csr":
         csr_now = gridder.csr
@@ -484,9 +491,27 @@ def run_rank(args):
             ref_gridder.pack(fields_d, masks_d, shared)
             ref_out = torch.empty_like(out)
             ref_gridder.apply(ref_out)
-            assert bool(torch.equal(ref_out.view(torch.int32), out.view(torch.int32))), \
-                "compact kernel and reference-format kernel disagree on the timed grid"
-            checked += "; rg_csr_compact_apply_f32 == rg_csr_apply_f32 bit for bit on all of them"
+            if kernel_name == "csr_compact_rowwise_kernel":
+                assert bool(torch.equal(torch.isnan(ref_out), torch.isnan(out))), "filled voxels differ from rg_csr_apply_f32"
+                scale = max(float(f_t[torch.isfinite(f_t)].abs().max()) for f_t in fields_d)
+                excess = torch.nan_to_num((out - ref_out).abs() - 1e-5 * ref_out.abs(), nan=0.0)
+                worst = float(excess.max())
+                assert worst <= 1e-5 * scale, "row-wise kernel and reference-format kernel differ beyond 1e-5"
+                sig = ref_out.abs() > 1e-3 * scale
+                rel = float(((out - ref_out).abs()[sig] / ref_out.abs()[sig]).max())
+                checked += (f"; row-wise kernel vs rg_csr_apply_f32 on all of them: same voxels filled, |diff| <= 1e-5*|ref| + "
+                            f"1e-5*max|field| everywhere (worst relative deviation where |ref| > 1e-3*max|field|: {rel:.1e})")
+                del excess, sig
+                gridder.tile = 384                       # and the tile kernel over the very same records: bit for bit
+                gridder.apply(out)
+                gridder.tile = 0
+                assert bool(torch.equal(ref_out.view(torch.int32), out.view(torch.int32))), \
+                    "tile kernel over the packed records and reference-format kernel disagree"
+                checked += "; tile kernel over the same packed records == rg_csr_apply_f32 bit for bit"
+            else:
+                assert bool(torch.equal(ref_out.view(torch.int32), out.view(torch.int32))), \
+                    "compact kernel and reference-format kernel disagree on the timed grid"
+                checked += "; compact tile kernel == rg_csr_apply_f32 bit for bit on all of them"
             del ref_out, ref_gridder
         del nonempty, filled
     launches_per_step = len(events) / max(args.steps, 1)
@@ -500,7 +525,9 @@ def run_rank(args):
                     + (f" (BASELINE config 5: {total_vol} seeded volumes, volume b -> rank b mod {world}, through "
                        f"batch.VolumeBatch)" if c5 else "") + f", mode={args.mode}")
         compact_on = args.mode == "csr" and gridder.compact is not None
-        workload_key = f"{args.config}/{'csr_compact' if compact_on else args.mode}/F{n_f}/B{n_vol}"
+        rowwise_on = compact_on and kernel_name == "csr_compact_rowwise_kernel"
+        workload_key = (f"{args.config}/{'csr_rowwise' if rowwise_on else 'csr_compact' if compact_on else args.mode}"
+                        f"/F{n_f}/B{n_vol}")
         traffic, traffic_source = pmc_traffic(workload_key)
         result = {
             "metric": "Mvoxels/s gridded (+ achieved HBM GB/s in roofline)",

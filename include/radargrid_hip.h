@@ -300,7 +300,7 @@ int rg_grid_filter(const void* src, int32_t data_is_f64, int64_t n, int32_t flag
 /* ---------------------------------------------------------------------------------------------------
  * K1c  csr_apply over a compact device copy of the CSR -- same results as rg_csr_apply_f32 for every field count,
  * bit for bit, from 6 instead of 8 streamed bytes per pair and one gather per DISTINCT gate of a chunk instead of one
- * per pair.  The grid is planes x lines x rows (n_vox = n_planes * lines_per_plane * line_len; nz x ny x nx for a radar
+ * per pair.  (Its packed form, rg_csr_compact_apply_packed_f32 below, is the faster one where the weights allow it.)  The grid is planes x lines x rows (n_vox = n_planes * lines_per_plane * line_len; nz x ny x nx for a radar
  * grid).  A chunk is a 2-D patch: segment sx (one of the ceil(line_len / 64) balanced pieces of a line, the unit one
  * wavefront of rg_csr_apply_f32 owns) of the RG_COMPACT_LINES consecutive lines yg*RG_COMPACT_LINES.. of one plane; chunks are
  * numbered c = (plane * ceil(lines_per_plane / RG_COMPACT_LINES) + yg) * ceil(line_len / 64) + sx.  Chunk c lists its
@@ -328,16 +328,28 @@ int rg_csr_compact_apply_f32(const void* indptr, int32_t indptr_is_i64, const ui
                              int32_t stride, int64_t n_gates, float fill_value, float* out, int32_t window_cap,
                              int32_t tile, rg_stream_t stream);
 
-/* Packed pair stream of the compact copy (single-field passes): positions and weights of three consecutive pairs of a
- * segment in one 16-byte record -- 5.33 bytes per pair instead of 6, streamed with one 16-byte load per lane.
+/* Packed pair stream of the compact copy: positions and weights of three consecutive pairs of a segment in one 16-byte
+ * record -- 5.33 bytes per pair instead of 6, streamed with one 16-byte load per lane.
  *   record = [w0:26 | p2 bits 0-5] [w1:26 | p2 bits 6-11] [w2:26 | p2 bits 12-15] [p0:16 | p1:16]   (4 x uint32)
  *   weight code = float32 bits of the weight - w_base; the caller guarantees that every code fits 26 bits (all weights
  *   positive and within 8 binades of w_base >> 23), which makes the coding lossless.
  * Segments (the <= 64 rows one wavefront owns) are numbered line-major, seg = line * ceil(line_len / 64) + sx; segment
- * seg owns records rec_ptr[seg] .. rec_ptr[seg+1], ceil(pairs / 3) of them (rec_ptr has segments + 1 entries, built by the
- * caller).  rg_csr_compact_pack fills `records` from local_idx + weights; rg_csr_compact_apply_packed_f32 grids 1-4 fused
- * fields through them: the results of rg_csr_compact_apply_f32 / rg_csr_apply_f32 for the same fields, bit for bit
- * (tile: 0 = 384 pairs, the tile of the other two kernels; 576 / 768 are single-field tuning variants). */
+ * seg owns records rec_ptr[seg] .. rec_ptr[seg+1], ceil(pairs / 3) of them and fewer than 2^27 (rec_ptr has segments + 1
+ * entries, built by the caller).  rg_csr_compact_pack fills `records` from local_idx + weights (error_flag: 1 = rec_ptr
+ * inconsistent with indptr, 2 = a weight outside the code, 4 = a segment with 2^27 records or more).
+ * rg_csr_compact_apply_packed_f32 grids 1-4 fused fields through the records (interpolate.py:69-104, the same masked
+ * weighted mean as rg_csr_apply_f32: float32 products and sums, float64 only in the final division):
+ *   tile = 0    the ROW-WISE kernel: the lanes of a row read the row's records straight from memory and sum them in
+ *               registers (no LDS tile), L = 2^k lanes per row chosen per segment from its mean row length.  The order
+ *               of the float32 adds is fixed by the geometry and the field count alone (reproducible run to run, on any
+ *               window_cap), but it is not the order of rg_csr_apply_f32: the two agree to float32 rounding (the bar of
+ *               the parity tests: 1e-5 relative + 1e-5 * max|field|), not bit for bit.  This is the fast path:
+ *               1.0-1.5 ms for 1-4 fields on BASELINE config 2 where the tile kernels need 1.1-3.3 ms.
+ *   tile = 384  the TILE kernel of rg_csr_compact_apply_f32 over the same records: the results of rg_csr_apply_f32 for the
+ *               same fields, bit for bit (576 / 768: single-field tuning variants of it).
+ *   tile = 2000 + h   row-wise with a diagnostic lane split: h = 1, 2, 4 .. 64 lanes per row, or h = 70 + t to aim for t
+ *               records per lane and row (another split = another order of the adds).
+ * window_cap as for rg_csr_compact_apply_f32; the row-wise kernel keeps one entry more (an all-EXCLUDED sentinel). */
 int rg_csr_compact_pack(const void* indptr, int32_t indptr_is_i64, const uint16_t* local_idx, const float* weights,
                         int64_t n_rows, int64_t line_len, int64_t lines_per_plane, const int64_t* rec_ptr,
                         uint32_t w_base, void* records, int32_t* error_flag, rg_stream_t stream);

@@ -164,6 +164,18 @@ def device(index=None):
     return torch.device("cuda", index)
 
 
+def canonical_device(dev):
+    """``torch.device("cuda")`` / ``"cuda:1"`` / an int -> the indexed ``torch.device``: tensors report ``cuda:N``, and an
+    index-less device compares unequal to it (a cache keyed on the device would otherwise never hit)."""
+    torch = torch_mod()
+    if dev is None:
+        return device()
+    dev = torch.device("cuda", dev) if isinstance(dev, int) else torch.device(dev)
+    if dev.type == "cuda" and dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    return dev
+
+
 def stream_ptr() -> int:
     """hipStream_t of torch's current stream (0 = the null stream)."""
     torch = torch_mod()

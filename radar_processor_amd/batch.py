@@ -121,7 +121,7 @@ class VolumeBatch:
         self.fused = isinstance(geometry, RoiSearch)
         self.weighting = weighting
         self.field_names = list(field_names)
-        self.dev = geometry.dev if self.fused else (_native.device() if device is None else device)
+        self.dev = geometry.dev if self.fused else _native.canonical_device(device)
         if not 1 <= len(self.field_names) <= _native.RG_MAX_FIELDS:
             raise ValueError("1..8 fields per volume")
         # measured on the bench grid (ms per fused pass, rg_csr_apply_f32): 1 field-volume 13.1 (9.5 through the compact

@@ -494,6 +494,7 @@ __global__ __launch_bounds__(256) void compact_pack_kernel(const IndT* __restric
   const long p0 = (long)indptr[r0], p1 = (long)indptr[r0 + nrows];
   const long rb = rec_ptr[seg], rn = rec_ptr[seg + 1] - rb;
   if (lane == 0 && rn != (p1 - p0 + 2) / 3) atomicOr(error_flag, 1);
+  if (lane == 0 && rn >= (1L << 27)) atomicOr(error_flag, 4);   // the apply kernels use 32-bit byte offsets per segment
   for (long r = lane; r < rn; r += 64) {
     unsigned code[3], pos[3];
 #pragma unroll
@@ -546,15 +547,340 @@ extern "C" int rg_csr_compact_pack(const void* indptr, int32_t indptr_is_i64, co
   return rg::check_launch("rg_csr_compact_pack");
 }
 
-// 1-4 fused fields over the packed stream (same results as rg_csr_compact_apply_f32 / rg_csr_apply_f32, bit for bit)
+// ---------------------------------------------------------------------------------------------------------------
+// Row-wise kernel over the packed stream (1-4 fields): the default of rg_csr_compact_apply_packed_f32.
+// The tile kernel above moves every pair through LDS twice (the product side writes the tile, the row side reads it
+// back): 8 bytes per pair each way for one field, 16 + 16 for three on top of the window gather, and from two fields on
+// it is LDS- and latency-bound, not HBM-bound.  A packed record already holds three CONSECUTIVE
+// pairs, so here the lanes of a row read the row's records straight from memory -- L = 2^k lanes per row, lane j takes
+// records q0 + j, q0 + j + L, ... of the row's record range [rs / 3, ceil(re / 3)) -- and reduce them in registers: no
+// tile, no transposition; LDS carries only the window gathers.  64 / L rows share a wave-load (L * 16 contiguous bytes
+// each, neighbouring rows adjacent in memory); a record that straddles two rows is read by both (an L1 hit) and each
+// takes its own pairs.  Pairs outside the lane's row are redirected to a sentinel window entry whose slots are all
+// EXCLUDED, so the arithmetic needs no extra test.
+// A STEP is one batch of KPRE record loads per lane; the loads of the next step (of the same rows, or of the next
+// 64 / L rows) are always requested before the current step is summed -- two register stages, as in the tile kernel.
+// Summation order (fixed by the geometry and the field count alone, so results are reproducible run to run, on any
+// window size and on the per-pair path of an over-wide chunk): per lane, its records in ascending order and a record's
+// pairs in order, one running (sum w*v, sum w) per field; then the xor butterfly of rg_row_phase.hpp over the L lanes.
+// L is chosen per segment from its mean row length (kTarget records per lane and row).  This is NOT the order of
+// rg_csr_apply_f32: the two agree to float32 rounding, not bit for bit (the tile kernel over the same records, tile =
+// 384, does).
+// Per field count (measured on config 2 and the bench grid, profiles/r02_rowwise_sweep.json):
+//   KPRE   records per lane and step;   kTarget  records per lane and row L aims for;
+//   kNarrow  12-byte window entries for three fields (three 4-byte LDS reads per pair instead of one 16-byte read,
+//            but a quarter less LDS per workgroup);
+//   kRegs    the row sums travel to lane == row by shuffle and wait in registers instead of an LDS array.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+template <int NF> struct RowwiseConfig;
+template <> struct RowwiseConfig<1> { static constexpr int kpre = 3, target = 4; static constexpr bool narrow = false, regs = false; };
+template <> struct RowwiseConfig<2> { static constexpr int kpre = 3, target = 6; static constexpr bool narrow = false, regs = false; };
+template <> struct RowwiseConfig<3> { static constexpr int kpre = 2, target = 6; static constexpr bool narrow = true, regs = true; };
+template <> struct RowwiseConfig<4> { static constexpr int kpre = 3, target = 8; static constexpr bool narrow = false, regs = true; };
+
+template <typename IndT, int NF, int STRIDE>
+__global__ __launch_bounds__(64 * kH) void csr_compact_rowwise_kernel(
+    const IndT* __restrict__ indptr, const int64_t* __restrict__ dict_ptr, const int32_t* __restrict__ dict, ChunkGrid cg,
+    const float* __restrict__ packed, unsigned last_gate, float fill, int window_cap, long n_vox, float* __restrict__ out,
+    const rg_u32x4* __restrict__ rec, const int64_t* __restrict__ rec_ptr, unsigned w_base, int lanes_hint) {
+  static_assert(NF >= 1 && NF <= 4 && (STRIDE == 1 || STRIDE == 2 || STRIDE == 4), "passes of 1-4 fields");
+  using Cfg = RowwiseConfig<NF>;
+  constexpr int KPRE = Cfg::kpre;
+  constexpr bool kNarrow = Cfg::narrow, kRegs = Cfg::regs;
+  extern __shared__ __attribute__((aligned(16))) float window[];   // window_cap + 1 entries of STRIDE (kNarrow: 3) floats
+  __shared__ f32x2 rowacc_all[kRegs ? 1 : kH][kRegs ? 2 : 64 * NF];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  f32x2* rowacc = rowacc_all[kRegs ? 0 : wv];
+  float mine_p[NF], mine_w[NF];                       // kRegs: lane == row
+#pragma unroll
+  for (int f = 0; f < NF; ++f) mine_p[f] = mine_w[f] = 0.0f;
+
+  const unsigned bid = blockIdx.x;           // block -> chunk: the rotation of csr_compact_kernel
+  const unsigned grp = bid / cg.nsx;
+  const unsigned col = bid - grp * cg.nsx;
+  const unsigned rot = (col + (grp * cg.rot_step) % cg.nsx);
+  const unsigned chunk = grp * cg.nsx + (rot >= cg.nsx ? rot - cg.nsx : rot);
+  const long d0 = dict_ptr[chunk];
+  const int nd_all = (int)(dict_ptr[chunk + 1] - d0);
+  const bool split = nd_all > 65536;
+  const bool windowed = nd_all <= window_cap;        // the window holds window_cap + 1 entries: the sentinel
+  const int w_lo = split ? dict[d0 + wv] : 0;
+  const int w_hi = split ? (wv + 1 < kH ? dict[d0 + wv + 1] : nd_all) : nd_all;
+  const int nd = w_hi - w_lo;
+  const int nd_last = nd > 0 ? nd - 1 : 0;
+  const int32_t* __restrict__ cdict = dict + d0 + w_lo;
+
+  const Segment sg = chunk_segment(cg, chunk, wv);
+  const int nrows = sg.nrows;
+  const long r0 = sg.r0;
+  const long seg_b = nrows ? (long)indptr[r0] : 0;
+  const long seg_e = nrows ? (long)indptr[r0 + nrows] : 0;
+  const int span = (int)(seg_e - seg_b);
+  const int rs_o = nrows ? (int)((long)indptr[r0 + (lane < nrows ? lane : nrows)] - seg_b) : 0;
+  const int re_o = nrows ? (int)((long)indptr[r0 + (lane + 1 < nrows ? lane + 1 : nrows)] - seg_b) : 0;
+  long rec_b = 0, rec_n = 0;
+  if (nrows) {
+    rec_b = rec_ptr[sg.seg];
+    rec_n = rec_ptr[sg.seg + 1] - rec_b;
+  }
+  const rsrc_t rr = make_rsrc(rec + rec_b, rec_n * 16);
+  constexpr int kOutOfRange = 0x7FFFFFF0;            // byte offset no segment reaches: the load returns zeros
+
+  // ---- lanes per row ------------------------------------------------------------------------------------------
+  int lgl;
+  if (lanes_hint > 0 && lanes_hint <= 64) {
+    lgl = 31 - __builtin_clz(lanes_hint);
+  } else {
+    const int target = lanes_hint > 70 ? lanes_hint - 70 : Cfg::target;   // records per lane and row to aim for
+    const int mean_rec = nrows ? span / (3 * nrows) + 1 : 1;      // records a row touches, about
+    const int need = (mean_rec + target - 1) / target;
+    lgl = need <= 1 ? 0 : 32 - __builtin_clz(need - 1);
+  }
+  lgl = __builtin_amdgcn_readfirstlane(lgl > 6 ? 6 : lgl);
+  const int nl = 1 << lgl, rpr = 64 >> lgl;          // lanes per row, rows per round
+  const int sub = lane & (nl - 1), rgrp = lane >> lgl;
+  const int rounds = (nrows + rpr - 1) >> (6 - lgl);
+  // trips of a round = the most records any of its rows gives one lane; lane == row here, groups of rpr rows
+  const unsigned q0_row = (unsigned)rs_o / 3u;
+  const unsigned q1_row = re_o > rs_o ? ((unsigned)re_o + 2u) / 3u : q0_row;
+  int trips_row = (int)((q1_row - q0_row + (unsigned)nl - 1u) >> lgl);
+  for (int m = 1; m < rpr; m <<= 1) {
+    const int o = __shfl_xor(trips_row, m, 64);
+    trips_row = o > trips_row ? o : trips_row;
+  }
+
+  // ---- the chunk's field window + the sentinel entry ----------------------------------------------------------
+  if (windowed) {
+    for (int i = threadIdx.x; i <= nd_all; i += 64 * kH) {
+      float v[STRIDE];
+      if (i < nd_all) {
+        const unsigned g0 = (unsigned)cdict[i];
+        rg::load_packed<STRIDE>(packed, g0 < last_gate ? g0 : last_gate, v);
+      } else {
+#pragma unroll
+        for (int s = 0; s < STRIDE; ++s) v[s] = __builtin_bit_cast(float, RG_EXCLUDED_BITS);
+      }
+      if constexpr (kNarrow) {
+        window[i * 3] = v[0]; window[i * 3 + 1] = v[1]; window[i * 3 + 2] = v[2];
+      } else if constexpr (STRIDE == 1) {
+        window[i] = v[0];
+      } else if constexpr (STRIDE == 2) {
+        reinterpret_cast<f32x2*>(window)[i] = (f32x2){v[0], v[1]};
+      } else {
+        reinterpret_cast<f32x4*>(window)[i] = (f32x4){v[0], v[1], v[2], v[3]};
+      }
+    }
+  }
+  __syncthreads();
+
+  // A STEP is one batch of KPRE record loads per lane: batch b of round rho.  A round whose rows need more than KPRE
+  // trips simply takes several steps, so every load of the kernel is requested one step ahead whatever the row lengths.
+  struct Step {
+    int qs, qe;        // the lane's row: pairs [qs, qe) of the segment
+    int q, q1;         // the lane's first record of this batch, end of the row's records
+    int myrow, rho;
+    int left;          // trips of the round still to do, this batch included (wave-uniform)
+    bool live;
+  };
+  auto setup = [&](int rho) -> Step {
+    Step r;
+    r.rho = rho;
+    r.myrow = rho * rpr + rgrp;
+    r.live = r.myrow < nrows;
+    r.qs = __shfl(rs_o, r.myrow & 63, 64);
+    const int qe = __shfl(re_o, r.myrow & 63, 64);
+    r.qe = r.live ? qe : r.qs;
+    const unsigned q0 = (unsigned)r.qs / 3u;
+    r.q1 = r.qe > r.qs ? (int)(((unsigned)r.qe + 2u) / 3u) : (int)q0;
+    r.q = (int)q0 + sub;
+    r.left = rho < rounds ? __builtin_amdgcn_readfirstlane(__shfl(trips_row, (rho * rpr) & 63, 64)) : 0;
+    return r;
+  };
+  auto advance = [&](const Step& r) -> Step {      // the step after r (wave-uniform choice)
+    if (r.left > KPRE) {
+      Step n = r;
+      n.q += KPRE << lgl;
+      n.left -= KPRE;
+      return n;
+    }
+    return setup(r.rho + 1);
+  };
+  auto issue = [&](const Step& r, rg_u32x4 (&regs)[KPRE]) {
+#pragma unroll
+    for (int k = 0; k < KPRE; ++k) {
+      const int qk = r.q + (k << lgl);
+      regs[k] = rg_buffer_load_v4u32(rr, qk < r.q1 ? qk * 16 : kOutOfRange, 0, 0);
+    }
+  };
+
+  auto run = [&](auto wtag) {
+    constexpr bool kWindowed = decltype(wtag)::value;
+    float ap[NF], aw[NF];                           // the running sums of the lane's row, across the round's steps
+#pragma unroll
+    for (int f = 0; f < NF; ++f) ap[f] = aw[f] = 0.0f;
+    auto consume = [&](const Step& r, const rg_u32x4& q4, int qk) {
+      const bool ok = qk < r.q1;
+      const int o = 3 * qk;
+      float w[3];
+      int pos[3];
+      w[0] = __builtin_bit_cast(float, (q4.x & 0x3FFFFFFu) + w_base);
+      w[1] = __builtin_bit_cast(float, (q4.y & 0x3FFFFFFu) + w_base);
+      w[2] = __builtin_bit_cast(float, (q4.z & 0x3FFFFFFu) + w_base);
+      pos[0] = (int)(q4.w & 0xFFFFu);
+      pos[1] = (int)(q4.w >> 16);
+      pos[2] = (int)((q4.x >> 26) | ((q4.y >> 26) << 6) | ((q4.z >> 26) << 12));
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const bool mine = ok && o + i >= r.qs && o + i < r.qe;
+        const int p = pos[i] < nd_last ? pos[i] : nd_last;
+        float v[STRIDE];
+        if constexpr (kWindowed) {
+          const int e = mine ? p : nd_all;          // not this row's pair: the all-EXCLUDED sentinel entry
+          if constexpr (kNarrow) {
+            v[0] = window[e * 3]; v[1] = window[e * 3 + 1]; v[2] = window[e * 3 + 2];
+          } else if constexpr (STRIDE == 1) {
+            v[0] = window[e];
+          } else if constexpr (STRIDE == 2) {
+            const f32x2 x = reinterpret_cast<const f32x2*>(window)[e];
+            v[0] = x.x; v[1] = x.y;
+          } else {
+            const f32x4 x = reinterpret_cast<const f32x4*>(window)[e];
+            v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+          }
+        } else {
+          const unsigned g0 = (unsigned)cdict[p];
+          rg::load_packed<STRIDE>(packed, g0 < last_gate ? g0 : last_gate, v);
+          if (!mine) {
+#pragma unroll
+            for (int s = 0; s < STRIDE; ++s) v[s] = __builtin_bit_cast(float, RG_EXCLUDED_BITS);
+          }
+        }
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {   // masked gate: contributes to neither sum (interpolate.py:78-79)
+          const bool good = rg::f32_bits(v[f]) != RG_EXCLUDED_BITS;
+          ap[f] += good ? w[i] * v[f] : 0.0f;
+          aw[f] += good ? w[i] : 0.0f;
+        }
+      }
+    };
+    // sums of step r's batch; `last`: the round ends here -> fold the row's lanes and hand the sums to the row
+    auto process = [&](const Step& r, const rg_u32x4 (&regs)[KPRE], bool last) {
+#pragma unroll
+      for (int k = 0; k < KPRE; ++k) {
+        if (k < r.left) consume(r, regs[k], r.q + (k << lgl));   // wave-uniform
+      }
+      if (!last) return;
+      float sv[2 * NF];
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        sv[2 * f] = ap[f];
+        sv[2 * f + 1] = aw[f];
+        ap[f] = aw[f] = 0.0f;
+      }
+      rg::butterfly<2 * NF>(sv, nl);
+      if constexpr (kRegs) {      // every lane of a row holds the row's sums: lane == row fetches them
+        const int first = r.myrow - rgrp;                   // the round's first row (wave-uniform)
+        const bool take = lane >= first && lane < first + rpr;
+        const int src = ((lane - first) << lgl) & 63;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          const float gp = __shfl(sv[2 * f], src, 64), gw = __shfl(sv[2 * f + 1], src, 64);
+          mine_p[f] = take ? gp : mine_p[f];
+          mine_w[f] = take ? gw : mine_w[f];
+        }
+      } else if (r.live && sub == 0) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) rowacc[r.myrow * NF + f] = (f32x2){sv[2 * f], sv[2 * f + 1]};
+      }
+    };
+
+    rg_u32x4 regs_a[KPRE], regs_b[KPRE];
+    Step sa = setup(0), sb;
+    issue(sa, regs_a);
+    for (;;) {     // two register stages, alternating: nothing in flight is ever copied
+      sb = advance(sa);
+      issue(sb, regs_b);
+      process(sa, regs_a, sb.rho != sa.rho);
+      if (sb.rho >= rounds) break;
+      sa = advance(sb);
+      issue(sa, regs_a);
+      process(sb, regs_b, sa.rho != sb.rho);
+      if (sa.rho >= rounds) break;
+    }
+  };
+  if (span > 0) {
+    if (windowed) run(std::true_type{}); else run(std::false_type{});
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  if (lane < nrows) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      f32x2 s = (f32x2)(0.0f);
+      if constexpr (kRegs) s = (f32x2){mine_p[f], mine_w[f]};
+      else if (span > 0) s = rowacc[lane * NF + f];
+      out[(size_t)f * n_vox + r0 + lane] = s.y > 0.0f ? (float)((double)s.x / (double)s.y) : fill;
+    }
+  }
+}
+
+template <typename IndT, int NF>
+int launch_rowwise(int window_cap, const void* indptr, const int64_t* dict_ptr, const int32_t* dict, const ChunkGrid& cg,
+                   long n_vox, const float* packed, long n_gates, float fill, float* out, hipStream_t s,
+                   const PackedStream& ps, int lanes_hint) {
+  constexpr int STRIDE = stride_for(NF);
+  constexpr int WS = RowwiseConfig<NF>::narrow ? 3 : STRIDE;                     // floats per window entry
+  constexpr long kStatic = RowwiseConfig<NF>::regs ? 16 : (long)kH * 64 * NF * 8;   // the row-sum array, if any
+  // one entry beyond window_cap: the sentinel; a smaller window only sends more chunks down the per-pair path
+  const long room = (65536 - kStatic - 256) / (4 * WS) - 1;
+  if (window_cap > room) window_cap = (int)room;
+  hipLaunchKernelGGL((csr_compact_rowwise_kernel<IndT, NF, STRIDE>), dim3((unsigned)chunk_count(cg)), dim3(64 * kH),
+                     ((size_t)(window_cap + 1) * WS * sizeof(float) + 15) / 16 * 16, s, static_cast<const IndT*>(indptr),
+                     dict_ptr, dict, cg, packed, (unsigned)(n_gates - 1), fill, window_cap, n_vox, out, ps.rec, ps.rec_ptr,
+                     ps.w_base, lanes_hint);
+  return rg::check_launch("rg_csr_compact_apply_packed_f32");
+}
+
+template <typename IndT>
+int launch_rowwise_nf(int nf, int window_cap, const void* indptr, const int64_t* dict_ptr, const int32_t* dict,
+                      const ChunkGrid& cg, long n_vox, const float* packed, long n_gates, float fill, float* out,
+                      hipStream_t s, const PackedStream& ps, int lanes_hint) {
+#define RG_ROW(NF_) \
+  launch_rowwise<IndT, NF_>(window_cap, indptr, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s, ps, lanes_hint)
+  switch (nf) {
+    case 1: return RG_ROW(1);
+    case 2: return RG_ROW(2);
+    case 3: return RG_ROW(3);
+    default: return RG_ROW(4);
+  }
+#undef RG_ROW
+}
+
+}  // namespace
+
+// 1-4 fields over the packed stream.  tile = 0: the row-wise kernel (agrees with rg_csr_apply_f32 to float32 rounding);
+// tile = 384 (one field: also 576 / 768): the tile kernel over the same records (agrees with it bit for bit);
+// tile = 2000 + h: row-wise with a diagnostic lane split (h = 1..64: that many lanes per row; h = 70 + t: aim for t
+// records per lane and row) -- a different split is a different order of the float32 adds.
 extern "C" int rg_csr_compact_apply_packed_f32(const void* indptr, int32_t indptr_is_i64, const void* records,
                                                const int64_t* rec_ptr, uint32_t w_base, const int64_t* dict_ptr,
                                                const int32_t* dict, int64_t n_vox, int64_t n_pairs, int64_t line_len,
                                                int64_t lines_per_plane, const float* packed, int32_t n_fields,
                                                int32_t stride, int64_t n_gates, float fill_value, float* out,
                                                int32_t window_cap, int32_t tile, rg_stream_t stream) {
-  RG_REQUIRE(tile == 0 || tile == 384 || ((tile == 576 || tile == 768) && n_fields == 1), RG_EINVAL,
-             "rg_csr_compact_apply_packed_f32: tile must be 0 / 384 (or, one field only, 576 / 768)");
+  const bool rowwise = tile == 0 || tile >= 2000;
+  const int lanes_hint = tile >= 2000 ? tile - 2000 : 0;
+  RG_REQUIRE(tile == 0 || tile == 384 || ((tile == 576 || tile == 768) && n_fields == 1) ||
+                 (tile >= 2000 && ((lanes_hint >= 1 && lanes_hint <= 64 && (lanes_hint & (lanes_hint - 1)) == 0) ||
+                                   (lanes_hint > 70 && lanes_hint <= 99))),
+             RG_EINVAL,
+             "rg_csr_compact_apply_packed_f32: tile must be 0 (row-wise kernel), 384 (tile kernel; one field: also 576 / "
+             "768) or 2000 + lane split");
   RG_REQUIRE(n_fields >= 1 && n_fields <= 4, RG_EUNSUPPORTED,
              "rg_csr_compact_apply_packed_f32: n_fields=%d not in 1..4 (5-8 fields use 128-pair tiles, not a whole number "
              "of 64-record loads)", n_fields);
@@ -580,6 +906,11 @@ extern "C" int rg_csr_compact_apply_packed_f32(const void* indptr, int32_t indpt
   ps.rec_ptr = rec_ptr;
   ps.w_base = w_base;
   hipStream_t s = (hipStream_t)stream;
+  if (rowwise)
+    return indptr_is_i64 ? launch_rowwise_nf<int64_t>(n_fields, window_cap, indptr, dict_ptr, dict, cg, n_vox, packed, n_gates,
+                                                      fill_value, out, s, ps, lanes_hint)
+                         : launch_rowwise_nf<int32_t>(n_fields, window_cap, indptr, dict_ptr, dict, cg, n_vox, packed, n_gates,
+                                                      fill_value, out, s, ps, lanes_hint);
 #define RG_K1P(IND_, NF_)                                                                                              \
   launch_nf<IND_, NF_, 384, 0, 0, true>(window_cap, indptr, nullptr, nullptr, dict_ptr, dict, cg, n_vox, packed, n_gates, \
                                         fill_value, out, s, ps)

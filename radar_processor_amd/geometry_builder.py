@@ -47,7 +47,7 @@ class RoiSearch:
                  beam_factor=0.01746, toa=17000.0, device=None, cell_size: Optional[float] = None):
         torch = _native.torch_mod()
         lib = _native.load_library()
-        self.dev = _native.device() if device is None else device
+        self.dev = _native.canonical_device(device)
         self.grid_shape = tuple(int(s) for s in grid_shape)
         self.grid_limits = grid_limits
         self.min_radius = float(min_radius)
@@ -259,7 +259,8 @@ def _build_compact_only(search: "RoiSearch", weighting: str, pairs_per_slab: int
                     _native.ptr(rec_ptr) + 8 * seg0, w_base, _native.ptr(rec), _native.ptr(err), stream),
                     "rg_csr_compact_pack")
                 if int(err.item()):
-                    logger.info("a weight does not fit the 26-bit code: keeping the plain compact layout instead")
+                    logger.info(f"rg_csr_compact_pack flag {int(err.item())} (a weight outside the 26-bit code, or an over-long "
+                                "segment): keeping the plain compact layout instead")
                     return None
                 del w_slab, l_slab
             del scratch

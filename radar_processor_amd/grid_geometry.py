@@ -108,6 +108,9 @@ class CompactCSR:
         line0 = torch.arange(nz * ny, device=dev, dtype=torch.int64) * nx
         edges = csr.indptr[(line0[:, None] + starts[None, :]).reshape(-1)].to(torch.int64).view(nz * ny, -1)
         n_rec_seg = ((edges[:, 1:] - edges[:, :-1]) + 2) // 3
+        if int(n_rec_seg.max()) >= 1 << 27:      # the kernels address a segment's records with 32-bit byte offsets
+            logger.info("a segment holds more than 2^27 records: the compact copy keeps the plain arrays")
+            return False
         rec_ptr = torch.zeros(n_rec_seg.numel() + 1, dtype=torch.int64, device=dev)
         rec_ptr[1:] = torch.cumsum(n_rec_seg.reshape(-1), 0)
         n_rec = int(rec_ptr[-1])
@@ -509,7 +512,7 @@ class GridGeometry:
 
     def device_csr(self, device=None) -> DeviceCSR:
         """CSR in HBM: uploaded (and validated) once, then cached on the object."""
-        dev = _native.device() if device is None else device
+        dev = _native.canonical_device(device)
         if self._dev is not None and self._dev.indptr.device == dev:
             return self._dev
         torch = _native.torch_mod()

@@ -71,15 +71,18 @@ class CsrGridder:
 
     def __init__(self, geometry: GridGeometry, n_gates: int, n_fields: int, device=None, compact: bool = False,
                  tile: int = 0, packed: bool = True):
-        """``compact``: run the pass through the compact device copy of the CSR (``rg_csr_compact_apply_f32``, built
-        and cached on the geometry the first time) when the geometry allows one and its LDS window for this field count
-        covers (nearly) all pairs; results are identical, bit for bit.  ``tile``: diagnostic override of the pipeline
-        tile (0 = default; non-default values change the order of the float32 adds)."""
+        """``compact``: run the pass through the compact device copy of the CSR (built and cached on the geometry the
+        first time) when the geometry allows one and its LDS window for this field count covers (nearly) all pairs:
+        ``rg_csr_compact_apply_packed_f32`` (row-wise kernel over the packed records; agrees with ``rg_csr_apply_f32`` to
+        float32 rounding) for 1-4 fields when the weights are codable and ``packed`` is set, ``rg_csr_compact_apply_f32``
+        (tile kernel; agrees bit for bit) otherwise.  ``tile``: diagnostic override -- 128...512 the pipeline tile of the
+        tile kernels (non-default values change the order of the float32 adds), 384 also selects the tile kernel over
+        the packed records, 2000 + h the lane split of the row-wise kernel."""
         torch = _native.torch_mod()
         self.lib = _native.load_library()
         if not 1 <= n_fields <= _native.RG_MAX_FIELDS:
             raise ValueError(f"n_fields must be in 1..{_native.RG_MAX_FIELDS}")
-        self.dev = _native.device() if device is None else device
+        self.dev = _native.canonical_device(device)
         self.csr = geometry.device_csr(self.dev)
         self.n_gates = int(n_gates)
         self.n_fields = int(n_fields)
@@ -98,28 +101,31 @@ class CsrGridder:
         if packed_only and self.n_fields > 4:
             raise _native.NativeError("this geometry holds only the packed pair stream, which serves passes of 1-4 fields; "
                                       "grid larger groups in several passes (grid_fields_device does)")
-        # Measured (config 2 / bench grid, ms per pass, standard vs compact kernel): 1 field 1.9 / 1.11 and 13.1 / 8.4,
-        # 2 fields 2.1 / 1.69 and 14.7 / 11.6, 3 fields 2.32 / 2.21 and 16.5 / 14.6, 4 fields 3.0 / 3.3 and 20.5 / 19.5,
-        # 8 fields 7.3 / 9.6 and 49.8 / 65.  What decides is the LDS window the compact kernel needs next to its tiles:
-        # up to about 24 KiB (bench grid: 768 entries x 16 bytes; config 2 with three fields: 1792 x 12) it keeps enough
-        # workgroups per CU to win, beyond that (config 2 with four fields: 28 KiB; any 8-field pass) the standard kernel
-        # -- no window -- does.  A compact-only geometry has no choice.
+        # Which kernel (ms per pass on config 2 / the bench grid, MI355X):
+        #                              1 field        2 fields       3 fields       4 fields       8 fields
+        #   rg_csr_apply_f32           1.9 / 13.1     2.1 / 14.7     2.3 / 16.5     3.0 / 20.5     7.3 / 49.8
+        #   compact, tile kernel       1.11 / 8.4     1.69 / 11.6    2.2 / 14.6     3.3 / 19.5     9.6 / 65
+        #   compact, row-wise kernel   1.02 / 7.9     1.13 / 8.7     1.29 / 10.1    1.50 / 11.4    (1-4 fields only)
+        # The row-wise kernel reads the packed records (weights codable in 26 bits: Barnes, nearest) and has no tile in
+        # LDS, so it wins at every window it can hold.  The tile kernel (weights not codable, or 5-8 fields) wins while its
+        # window stays <= 24 KiB next to its tiles and loses beyond; a compact-only geometry has no choice.
         want = compact or compact_only
         self.compact = geometry.device_compact(self.dev) if (want and self.csr.n_pairs) else None
-        if (self.compact is not None and not compact_only
-                and self.compact.window_for(self.n_fields) * self.compact.entry_bytes(self.n_fields)
-                > _COMPACT_MAX_WINDOW_BYTES):
-            self.compact = None
         self.window = 0
+        self.packed_stream = False
         if self.compact is not None:
             self.window = self.compact.window_for(self.n_fields)
             if not compact_only and self.compact.fallback_fraction(self.window) > _COMPACT_MAX_FALLBACK:
                 # too many chunks would gather per pair (dense scans next to many fields): the standard kernel is faster
                 self.compact, self.window = None, 0
-        # passes of 1-4 fields stream the packed records (positions + weights, 5.33 bytes per pair) when the geometry's
-        # weights allow the lossless 26-bit code and the memory is there; identical bits either way
-        self.packed_stream = ((packed or packed_only) and self.compact is not None and self.n_fields <= 4
-                              and self.compact.ensure_packed(self.csr))
+        if self.compact is not None:
+            # passes of 1-4 fields stream the packed records (positions + weights, 5.33 bytes per pair) when the geometry's
+            # weights allow the lossless 26-bit code and the memory is there
+            self.packed_stream = bool((packed or packed_only) and self.n_fields <= 4
+                                      and self.compact.ensure_packed(self.csr))
+            if (not self.packed_stream and not compact_only
+                    and self.window * self.compact.entry_bytes(self.n_fields) > _COMPACT_MAX_WINDOW_BYTES):
+                self.compact, self.window = None, 0
 
     def _check_fields(self, fields, masks, shared_mask):
         torch = _native.torch_mod()
@@ -148,17 +154,19 @@ class CsrGridder:
                                                   _native.ptr(self.packed), _native.stream_ptr()), "rg_pack_fields_f32")
 
     def apply(self, out, fill_value: float = np.nan) -> None:
-        """One pass over the CSR for all packed fields -> ``out[F, n_vox]`` (``rg_csr_compact_apply_f32`` through the
-        compact copy, ``rg_csr_apply_f32`` otherwise)."""
+        """One pass over the CSR for all packed fields -> ``out[F, n_vox]`` (``rg_csr_compact_apply_packed_f32`` /
+        ``rg_csr_compact_apply_f32`` through the compact copy, ``rg_csr_apply_f32`` otherwise)."""
         csr = self.csr
         nz, ny, nx = self.grid_shape
-        if self.compact is not None and self.packed_stream and (self.tile in (0, 576, 768) or csr.weights is None):
+        if self.compact is not None and self.packed_stream and (self.tile in (0, 384, 576, 768) or self.tile >= 2000
+                                                                or csr.weights is None):
             c = self.compact
             _native.check(self.lib.rg_csr_compact_apply_packed_f32(
                 _native.ptr(csr.indptr), int(csr.is_i64), _native.ptr(c.rec), _native.ptr(c.rec_ptr), c.w_base,
                 _native.ptr(c.dict_ptr), _native.ptr(c.dict), self.n_vox, csr.n_pairs, nx, ny, _native.ptr(self.packed),
                 self.n_fields, self.stride, self.n_gates, float(np.float32(fill_value)), _native.ptr(out), self.window,
-                self.tile if self.tile in (576, 768) else 0, _native.stream_ptr()), "rg_csr_compact_apply_packed_f32")
+                self.tile if (self.tile in (384, 576, 768) or self.tile >= 2000) else 0, _native.stream_ptr()),
+                "rg_csr_compact_apply_packed_f32")
             return
         if self.compact is not None:
             c = self.compact
@@ -217,6 +225,20 @@ def _use_compact(geometry: GridGeometry, dev) -> bool:
     return free_b > 3.2 * n_pairs + (8 << 30)
 
 
+def _fields_per_pass(geometry: GridGeometry, dev, use_compact: bool) -> int:
+    """Fields one CSR pass should fuse: 4 when the passes run through the packed records (the row-wise kernel takes 1-4
+    fields and two passes of four cost less than one of eight through any other kernel: 2 x 11.4 against 49.8 ms on the
+    bench grid), 8 (``RG_MAX_FIELDS``) otherwise."""
+    csr = geometry.device_csr(dev)
+    if csr.weights is None:                 # packed-only geometry
+        return 4
+    if use_compact and csr.n_pairs:
+        compact = geometry.device_compact(dev)
+        if compact is not None and compact.ensure_packed(csr):
+            return 4
+    return _native.RG_MAX_FIELDS
+
+
 def _cached_gridder(geometry: GridGeometry, n_gates: int, n_fields: int, dev, compact: bool) -> "CsrGridder":
     """One :class:`CsrGridder` (and its packed-field staging buffer) per (device CSR, gate count, field count, kernel)
     of a geometry, kept on the geometry object: repeated ``apply_geometry`` calls allocate nothing.  The cache dies with
@@ -263,12 +285,12 @@ def grid_fields_device(geometry: GridGeometry, fields: Sequence, masks: Optional
     elif not (out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and out.numel() == n_fields * n_vox):
         raise ValueError("out must be a contiguous cuda float32 tensor of shape [F, nz, ny, nx]")
     n_gates = int(fields[0].numel())
-    per_pass = 4 if geometry.device_csr(dev).weights is None else _native.RG_MAX_FIELDS   # packed-only: 1-4 per pass
     with torch.cuda.device(dev):
+        use_compact = _use_compact(geometry, dev)
+        per_pass = _fields_per_pass(geometry, dev, use_compact)
         for f0 in range(0, n_fields, per_pass):
             f1 = min(n_fields, f0 + per_pass)
-            gridder = _cached_gridder(geometry, n_gates, f1 - f0, dev,
-                                      compact=_use_compact(geometry, dev))
+            gridder = _cached_gridder(geometry, n_gates, f1 - f0, dev, compact=use_compact)
             gridder.pack(fields[f0:f1], masks[f0:f1], shared_mask)
             gridder.apply(out.view(n_fields, n_vox)[f0:f1], fill_value)
     return out.view(n_fields, nz, ny, nx)

@@ -31,7 +31,7 @@ class VolumePipeline:
                  fill_value: float = np.nan, use_graph: bool = True, device=None, compact: bool = False):
         torch = _native.torch_mod()
         self.lib = _native.load_library()
-        self.dev = _native.device() if device is None else device
+        self.dev = _native.canonical_device(device)
         self.geometry = geometry
         # compact=True: single-field pipelines over a large geometry grid through its compact CSR copy (identical bits)
         self.gridder = CsrGridder(geometry, n_gates, n_fields, device=self.dev, compact=compact)

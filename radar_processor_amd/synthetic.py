@@ -228,7 +228,7 @@ def gate_coordinates_device(elev_deg, az_deg, ranges_m, device=None):
     from . import _native
     torch = _native.torch_mod()
     lib = _native.load_library()
-    dev = _native.device() if device is None else device
+    dev = _native.canonical_device(device)
     elev = np.asarray(elev_deg, dtype=np.float64)
     az = np.asarray(az_deg, dtype=np.float64)
     rng_m = np.ascontiguousarray(ranges_m, dtype=np.float64)

@@ -92,3 +92,18 @@ def has_gpu():
         return torch.cuda.is_available()
     except Exception:
         return False
+
+
+def assert_same_to_rounding(got, want, scale, fill=None, rtol=1e-5):
+    """Two grids summed in different float32 orders (the row-wise kernel against the tile kernels / the oracle): the same
+    voxels filled, and every value within ``rtol * |want| + rtol * scale`` (``scale`` = the largest |value| of the field:
+    a weighted mean of mixed-sign data that cancels has no relative floor).  Accepts numpy arrays or torch tensors."""
+    if hasattr(got, "detach"):
+        got = got.detach().cpu().numpy()
+    if hasattr(want, "detach"):
+        want = want.detach().cpu().numpy()
+    if fill is None or np.isnan(fill):
+        np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+    else:
+        np.testing.assert_array_equal(got == np.float32(fill), want == np.float32(fill))
+    np.testing.assert_allclose(got, want, rtol=rtol, atol=rtol * float(scale), equal_nan=True)

@@ -5,6 +5,7 @@ no gate in reach, everything masked, top-of-atmosphere cuts, non-finite coordina
 import numpy as np
 import pytest
 
+from conftest import assert_same_to_rounding
 from oracle import radar_grid_oracle as oracle
 
 pytestmark = pytest.mark.gpu
@@ -212,12 +213,28 @@ def test_argument_validation_on_the_device_layer(rg):
                                   weighting="gaussian")
 
 
+def test_device_copies_are_cached_whatever_the_device_spelling(rg, tmp_path):
+    """torch.device("cuda"), "cuda:0", 0 and None name the same GPU: one device CSR, one compact copy (an index-less
+    device compares unequal to a tensor's cuda:0, which used to replicate the CSR on every call)."""
+    import torch
+    gx, gy, gz, val, mask = _cloud(3, 2000)
+    geom = rg.compute_grid_geometry(gx, gy, gz, (1, 8, 70), ((500.0, 500.0), (-3e3, 9e3), (-15e3, 15e3)), str(tmp_path),
+                                    min_radius=1500.0, beam_factor=0.05)
+    first = geom.device_csr(torch.device("cuda"))
+    for spelling in (torch.device("cuda", 0), "cuda:0", 0, None, torch.device("cuda")):
+        assert geom.device_csr(spelling) is first
+    compact = geom.device_compact(torch.device("cuda"))
+    assert compact is not None and geom.device_compact(torch.device("cuda", 0)) is compact
+
+
 @pytest.mark.parametrize("shape", [(1, 1, 1), (1, 3, 255), (2, 1, 257), (1, 5, 512), (3, 7, 300)])
 def test_compact_csr_edge_shapes(rg, tmp_path, shape):
     """Compact copy on grids whose lines are not a multiple of 64 rows and whose planes are not a multiple of 4 lines
     (short segments, chunks with fewer than 4 live wavefronts), with int32 and int64 row pointers, empty rows and a
-    custom fill value: bit-identical to the standard kernel for 1-8 fused fields, both with the LDS window and on the
-    per-pair fallback."""
+    custom fill value.  The tile kernel (plain arrays, and the packed records with tile=384) is bit-identical to the
+    standard kernel for 1-8 fused fields, both with the LDS window and on the per-pair fallback; the row-wise kernel over
+    the packed records (the default for 1-4 fields) agrees to float32 rounding, and bit for bit with itself whatever the
+    window."""
     import torch
     from radar_processor_amd import _native
     from radar_processor_amd.gridding import CsrGridder
@@ -236,12 +253,12 @@ def test_compact_csr_edge_shapes(rg, tmp_path, shape):
                                                                    csr.max_gate), 17000.0)
         else:
             g2 = geom
-        g_c = CsrGridder(g2, f.numel(), 1, device=dev, compact=True)
+        g_c = CsrGridder(g2, f.numel(), 1, device=dev, compact=True, packed=False)
         g_s = CsrGridder(g2, f.numel(), 1, device=dev)
         if g_s.csr.n_pairs == 0:
             assert g_c.compact is None
             continue
-        assert g_c.compact is not None
+        assert g_c.compact is not None and not g_c.packed_stream
         g_c.pack([f], [m]); g_s.pack([f], [m])
         want = torch.empty((1, g_s.n_vox), dtype=torch.float32, device=dev)
         got = torch.empty_like(want)
@@ -275,7 +292,7 @@ def test_compact_csr_edge_shapes(rg, tmp_path, shape):
         emask = [torch.from_numpy(np.roll(mask, 13 * (i + 1)).astype(np.uint8)).to(dev) if i % 2 else None for i in range(7)]
         for nf in (2, 3, 4, 5, 8):
             fl, ml = [f] + extra[:nf - 1], [m] + emask[:nf - 1]
-            gm_c = CsrGridder(g2, f.numel(), nf, device=dev, compact=True)
+            gm_c = CsrGridder(g2, f.numel(), nf, device=dev, compact=True, packed=False)
             gm_s = CsrGridder(g2, f.numel(), nf, device=dev)
             assert gm_s.compact is None
             gm_c.compact, gm_c.window = c, c.window_for(nf)   # even if the policy would have preferred the standard kernel
@@ -288,6 +305,30 @@ def test_compact_csr_edge_shapes(rg, tmp_path, shape):
             got_m.fill_(3.0)
             compact_apply(gm_c, got_m, 0, 0)
             assert torch.equal(got_m.view(torch.int32), want_m.view(torch.int32)), nf
+            if nf > 4:
+                continue
+            # the packed records: tile kernel (tile=384) bit for bit, row-wise kernel (default) to rounding -- and the
+            # row-wise kernel bit for bit with itself on the per-pair path (window 0) and from run to run
+            gm_r = CsrGridder(g2, f.numel(), nf, device=dev, compact=True)
+            assert gm_r.compact is c and gm_r.packed_stream
+            gm_r.packed = gm_s.packed
+            gm_r.tile = 384
+            got_m.fill_(3.0)
+            gm_r.apply(got_m, fill_value=-1.0)
+            assert torch.equal(got_m.view(torch.int32), want_m.view(torch.int32)), nf
+            gm_r.tile = 0
+            got_m.fill_(3.0)
+            gm_r.apply(got_m, fill_value=-1.0)
+            assert_same_to_rounding(got_m, want_m, scale=float(np.abs(val).max()) * nf, fill=-1.0)
+            again = torch.full_like(got_m, 3.0)
+            gm_r.window = 0
+            gm_r.apply(again, fill_value=-1.0)
+            assert torch.equal(again.view(torch.int32), got_m.view(torch.int32)), nf
+        g_r = CsrGridder(g2, f.numel(), 1, device=dev, compact=True)      # one field, row-wise
+        assert g_r.packed_stream
+        g_r.pack([f], [m])
+        g_r.apply(got, fill_value=-1.0)
+        assert_same_to_rounding(got, want, scale=float(np.abs(val).max()), fill=-1.0)
 
 
 def test_compact_csr_rich_chunks(rg):
@@ -351,6 +392,17 @@ def test_compact_csr_rich_chunks(rg):
         got2 = torch.full_like(want2, 5.0)
         g_s2.apply(want2); g_c2.apply(got2)
         assert torch.equal(got2.view(torch.int32), want2.view(torch.int32)), nf
+        # the packed records of a split chunk: tile kernel bit for bit, row-wise kernel to rounding
+        assert split.ensure_packed(csr2)
+        g_c2.packed_stream = True
+        for tile, exact in ((384, True), (0, False)):
+            g_c2.tile = tile
+            got2.fill_(5.0)
+            g_c2.apply(got2)
+            if exact:
+                assert torch.equal(got2.view(torch.int32), want2.view(torch.int32)), nf
+            else:
+                assert_same_to_rounding(got2, want2, scale=2.0 * float(vals2.abs().max()))
     four = CompactCSR.build(csr2, (4, 1, 64))                   # the same rows as four one-line chunks: 19 200 gates each
     assert four is not None and four.max_dict == 19200 and torch.equal(four.decode(csr2), rich)
     # a single 64-row segment with more than 65536 distinct gates: not compactable, the standard kernel stays in charge
@@ -364,8 +416,9 @@ def test_compact_csr_rich_chunks(rg):
 def test_compact_and_packed_kernels_fuzz(rg, seed):
     """Random hand-made CSRs -- random grid shapes (lines that are not multiples of 64 rows, planes that are not
     multiples of 4 lines), empty rows, rows longer than a tile, few or many distinct gates per chunk, int32 / int64 row
-    pointers, 1-4 fused fields -- through the plain compact kernel, the packed stream and the packed-only decode, all
-    bit for bit against the standard kernel / the original arrays."""
+    pointers, 1-4 fused fields -- through the plain compact kernel, the tile kernel over the packed stream and the
+    packed-only decode, all bit for bit against the standard kernel / the original arrays; and through the row-wise kernel
+    over the packed stream (the default), equal to float32 rounding and bit for bit with itself on the per-pair path."""
     import torch
     from radar_processor_amd.gridding import CsrGridder
     from radar_processor_amd.grid_geometry import CompactCSR, DeviceCSR, GridGeometry
@@ -406,11 +459,13 @@ def test_compact_and_packed_kernels_fuzz(rg, seed):
     for nf in (1, 2, 3, 4):
         g_s = CsrGridder(geom, n_gates, nf, device=dev)
         g_p = CsrGridder(geom, n_gates, nf, device=dev)
-        g_p.compact, g_p.window, g_p.packed_stream = compact, compact.window_for(nf), True
+        g_p.compact, g_p.window, g_p.packed_stream, g_p.tile = compact, compact.window_for(nf), True, 384
+        g_r = CsrGridder(geom, n_gates, nf, device=dev)
+        g_r.compact, g_r.window, g_r.packed_stream = compact, compact.window_for(nf), True
         g_c = CsrGridder(geom, n_gates, nf, device=dev)
         g_c.compact, g_c.window, g_c.packed_stream = compact, compact.window_for(nf), False
         want = torch.empty((nf, n_vox), dtype=torch.float32, device=dev)
-        for gr in (g_s, g_p, g_c):
+        for gr in (g_s, g_p, g_c, g_r):
             gr.pack(fields[:nf], masks[:nf])
         g_s.apply(want, fill_value=-3.0)
         for name, gr in (("packed", g_p), ("compact", g_c)):
@@ -422,6 +477,14 @@ def test_compact_and_packed_kernels_fuzz(rg, seed):
         got = torch.full_like(want, 9.0)
         g_p.apply(got, fill_value=-3.0)
         assert torch.equal(got.view(torch.int32), want.view(torch.int32)), ("packed, no window", nf, shape)
+        # the row-wise kernel: another order of the float32 adds
+        row = torch.full_like(want, 9.0)
+        g_r.apply(row, fill_value=-3.0)
+        assert_same_to_rounding(row, want, scale=100.0, fill=-3.0)
+        g_r.window = 0
+        got.fill_(9.0)
+        g_r.apply(got, fill_value=-3.0)
+        assert torch.equal(got.view(torch.int32), row.view(torch.int32)), ("row-wise, no window", nf, shape)
     # and against the float64 oracle (tolerance: float32 accumulation)
     data = fields[0].cpu().numpy()
     want64 = oracle.csr_apply_f64(indptr, gidx, wts, data, masks[0].cpu().numpy().astype(bool), shape, fill_value=-3.0)

@@ -9,6 +9,7 @@ these sizes in seconds):
 import numpy as np
 import pytest
 
+from conftest import assert_same_to_rounding
 from oracle import radar_grid_oracle as oracle
 
 pytestmark = pytest.mark.gpu
@@ -173,16 +174,17 @@ def test_c2_compact_csr_is_bit_identical(c2):
     """rg_csr_compact_apply_f32 (16-bit dictionary positions, LDS field window) against rg_csr_apply_f32 on the full
     config-2 geometry: the dictionaries reproduce the gate indices exactly and the grids agree bit for bit -- with the
     geometry's own window size, with a window too small for most chunks, and with no window at all (every chunk on
-    the per-pair fallback); one field and the fused three-field pass of config 3."""
+    the per-pair fallback); one field and the fused three-field pass of config 3.  The packed records: the tile kernel
+    agrees bit for bit too, the row-wise kernel (the default) to float32 rounding."""
     from radar_processor_amd import _native
     from radar_processor_amd.grid_geometry import CompactCSR
     from radar_processor_amd.gridding import CsrGridder
     rg, torch, geom, dev = c2["rg"], c2["torch"], c2["geom"], c2["dev"]
     nz, ny, nx = c2["cfg"]["grid_shape"]
     f, m = c2["fields"]["DBZH"], c2["masks"]["DBZH"]
-    g_c = CsrGridder(geom, f.numel(), 1, device=dev, compact=True)
+    g_c = CsrGridder(geom, f.numel(), 1, device=dev, compact=True, packed=False)
     g_s = CsrGridder(geom, f.numel(), 1, device=dev)
-    assert g_c.compact is not None and g_s.compact is None
+    assert g_c.compact is not None and not g_c.packed_stream and g_s.compact is None
     csr, c = g_c.csr, g_c.compact
     assert c.local_idx.numel() == csr.n_pairs and int(c.dict_ptr[-1]) == c.n_dict
     assert c.dict_ptr.numel() == CompactCSR.layout((nz, ny, nx))[2] + 1
@@ -233,11 +235,13 @@ def test_c2_compact_csr_is_bit_identical(c2):
     # config 3: DBZH + ZDR + RHOHV with the RHOHV >= 0.8 mask, one fused pass through the compact copy
     names = ["DBZH", "ZDR", "RHOHV"]
     qc = rg.device_gate_mask(c2["fields"]["RHOHV"], "below", 0.8)
-    m_c = CsrGridder(geom, f.numel(), 3, device=dev, compact=True)
+    m_c = CsrGridder(geom, f.numel(), 3, device=dev, compact=True, packed=False)
     m_s = CsrGridder(geom, f.numel(), 3, device=dev)
-    assert m_c.compact is c and m_c.packed_stream and m_s.compact is None   # 3 fields: 21 KiB of window, packed stream
+    assert m_c.compact is c and not m_c.packed_stream and m_s.compact is None   # 3 fields: 21 KiB of window
+    # policy: 4 fused fields (28 KiB window) run the standard kernel unless the row-wise kernel (no tiles in LDS) can
+    assert CsrGridder(geom, f.numel(), 4, device=dev, compact=True, packed=False).compact is None
     four = CsrGridder(geom, f.numel(), 4, device=dev, compact=True)
-    assert four.compact is None                            # policy: 4 fused fields (28 KiB window) run the standard kernel
+    assert four.compact is c and four.packed_stream
     for gr in (m_c, m_s):
         gr.pack([c2["fields"][n] for n in names], [c2["masks"][n] for n in names], qc)
     want3 = torch.empty((3, m_s.n_vox), dtype=torch.float32, device=dev)
@@ -248,11 +252,35 @@ def test_c2_compact_csr_is_bit_identical(c2):
     got3.fill_(-7.0)
     compact_apply(m_c, got3, 256)
     assert bool(torch.equal(got3.view(torch.int32), want3.view(torch.int32)))
+    # the packed records (1 and 3 fields): tile kernel bit for bit; row-wise kernel to rounding, reproducible, and the
+    # same bits with a window too small for most chunks
+    scale = max(float(c2["fields"][n][torch.isfinite(c2["fields"][n])].abs().max()) for n in names)
+    for gr_s, want_s in ((g_s, want), (m_s, want3)):
+        g_r = CsrGridder(geom, f.numel(), gr_s.n_fields, device=dev, compact=True)
+        assert g_r.compact is c and g_r.packed_stream
+        g_r.packed = gr_s.packed
+        gr_s.apply(want_s)
+        got_r = torch.full_like(want_s, -7.0)
+        g_r.tile = 384
+        g_r.apply(got_r)
+        assert bool(torch.equal(got_r.view(torch.int32), want_s.view(torch.int32)))
+        g_r.tile = 0
+        got_r.fill_(-7.0)
+        g_r.apply(got_r)
+        assert_same_to_rounding(got_r, want_s, scale)
+        again = torch.full_like(want_s, -7.0)
+        g_r.apply(again)
+        assert bool(torch.equal(again.view(torch.int32), got_r.view(torch.int32)))
+        g_r.window = 256
+        again.fill_(-7.0)
+        g_r.apply(again)
+        assert bool(torch.equal(again.view(torch.int32), got_r.view(torch.int32)))
 
 
 def test_c2_passes_switch_to_the_compact_copy(c2):
     """gridding._use_compact: the first pass of a geometry runs the standard kernel, the second builds the compact copy
-    and every later pass -- single- or multi-field -- uses it.  Same bits every time."""
+    and every later pass -- single- or multi-field -- uses it (row-wise kernel over the packed records: the same values
+    to float32 rounding, the same bits from then on)."""
     rg, torch, dev = c2["rg"], c2["torch"], c2["dev"]
     from radar_processor_amd.grid_geometry import GridGeometry
     geom = GridGeometry.from_device(c2["geom"].grid_shape, c2["geom"].grid_limits, c2["geom"].device_csr(dev), 17000.0)
@@ -263,17 +291,19 @@ def test_c2_passes_switch_to_the_compact_copy(c2):
     assert geom._compact is not None and geom._compact[1] is not None
     second = rg.grid_fields_device(geom, [f], [m]).clone()
     two_b = rg.grid_fields_device(c2["geom"], [f, c2["fields"]["DBZH"]], [m, None])     # standard kernel (first use)
-    assert torch.equal(first.view(torch.int32), second.view(torch.int32))
-    assert torch.equal(two_a.view(torch.int32), two_b.view(torch.int32))
+    scale = float(c2["fields"]["DBZH"][torch.isfinite(c2["fields"]["DBZH"])].abs().max())
+    assert_same_to_rounding(second, first, scale)
+    assert_same_to_rounding(two_a, two_b, scale)
     assert len(geom._gridders) >= 2                                 # gridders (and staging buffers) are reused
     third = rg.grid_fields_device(geom, [f], [m])
-    assert torch.equal(first.view(torch.int32), third.view(torch.int32))
+    assert torch.equal(second.view(torch.int32), third.view(torch.int32))
 
 
 def test_c2_compact_only_layout(c2, tmp_path):
     """compute_grid_geometry(layout="compact"): the int32 index array is never materialised for the whole grid; row
     pointers and weights equal the standard build bit for bit, the decoded indices equal its gate_indices, gridding
-    gives the same bits, multi-field passes are refused, and layout="auto" keeps the standard arrays when they fit."""
+    gives the same values (to float32 rounding: its passes run the row-wise kernel), and layout="auto" keeps the
+    standard arrays when they fit."""
     rg, torch, dev, vol, cfg = c2["rg"], c2["torch"], c2["dev"], c2["vol"], c2["cfg"]
     std = c2["geom"].device_csr(dev)
     geom = rg.compute_grid_geometry(vol.gate_x, vol.gate_y, vol.gate_z, cfg["grid_shape"], cfg["grid_limits"],
@@ -288,12 +318,23 @@ def test_c2_compact_only_layout(c2, tmp_path):
     r0, r1 = 7 * nx + 13, 1234 * nx + 5          # a row range that cuts through chunks (4 lines x 64 rows)
     assert torch.equal(compact.decode(csr, r0, r1), std.gate_indices[int(std.indptr[r0]):int(std.indptr[r1])])
     f, m = c2["fields"]["DBZH"], c2["masks"]["DBZH"]
-    want = rg.grid_fields_device(c2["geom"], [f], [m])
+    from radar_processor_amd.gridding import CsrGridder
+    scale = float(f[torch.isfinite(f)].abs().max())
+    g_s = CsrGridder(c2["geom"], f.numel(), 2, device=dev)                    # the standard kernel
+    g_s.pack([f, c2["fields"]["ZDR"]], [m, None])
+    want2 = torch.empty((2, g_s.n_vox), dtype=torch.float32, device=dev)
+    g_s.apply(want2)
     got = rg.grid_fields_device(geom, [f], [m])
-    assert torch.equal(got.view(torch.int32), want.view(torch.int32))
-    want2 = rg.grid_fields_device(c2["geom"], [f, c2["fields"]["ZDR"]], [m, None])
+    assert_same_to_rounding(got.view(1, -1), want2[:1], scale)
     got2 = rg.grid_fields_device(geom, [f, c2["fields"]["ZDR"]], [m, None])      # multi-field works on the compact copy too
-    assert torch.equal(got2.view(torch.int32), want2.view(torch.int32))
+    assert_same_to_rounding(got2.view(2, -1), want2, scale)
+    # and bit for bit through the tile kernel of the compact copy (plain position / weight arrays)
+    g_t = CsrGridder(geom, f.numel(), 2, device=dev, packed=False)
+    assert g_t.compact is not None and not g_t.packed_stream
+    g_t.packed = g_s.packed
+    got_t = torch.empty_like(want2)
+    g_t.apply(got_t)
+    assert torch.equal(got_t.view(torch.int32), want2.view(torch.int32))
     auto = rg.compute_grid_geometry(vol.gate_x, vol.gate_y, vol.gate_z, cfg["grid_shape"], cfg["grid_limits"],
                                     str(tmp_path), layout="auto")
     assert auto.device_csr(dev).gate_indices is not None
@@ -305,8 +346,9 @@ def test_c2_compact_only_layout(c2, tmp_path):
 def test_c2_packed_only_layout(c2, tmp_path):
     """compute_grid_geometry(layout="packed"): only the row pointers, the dictionaries and the packed pair stream exist
     (positions + losslessly coded weights, three pairs per 16-byte record).  The decoded indices AND weights equal the
-    standard build bit for bit, 1-4 fused fields grid to the same bits as the standard kernel, larger groups are split,
-    and a weighting whose weights do not fit the 26-bit code (Cressman) falls back to the compact layout."""
+    standard build bit for bit, 1-4 fused fields grid to the same bits as the standard kernel through the tile kernel
+    and to the same values (float32 rounding) through the default row-wise kernel, larger groups are split, and a
+    weighting whose weights do not fit the 26-bit code (Cressman) falls back to the compact layout."""
     rg, torch, dev, vol, cfg = c2["rg"], c2["torch"], c2["dev"], c2["vol"], c2["cfg"]
     std = c2["geom"].device_csr(dev)
     geom = rg.compute_grid_geometry(vol.gate_x, vol.gate_y, vol.gate_z, cfg["grid_shape"], cfg["grid_limits"],
@@ -325,12 +367,28 @@ def test_c2_packed_only_layout(c2, tmp_path):
     names = ["DBZH", "ZDR", "RHOHV"]
     f = [c2["fields"][n] for n in names]
     m = [c2["masks"][n] for n in names]
+    from radar_processor_amd.gridding import CsrGridder
+    scale = max(float(t[torch.isfinite(t)].abs().max()) for t in f)
     for nf in (1, 2, 3):
-        want = rg.grid_fields_device(c2["geom"], f[:nf], m[:nf])
+        g_s = CsrGridder(c2["geom"], f[0].numel(), nf, device=dev)            # the standard kernel
+        g_s.pack(f[:nf], m[:nf])
+        want = torch.empty((nf, g_s.n_vox), dtype=torch.float32, device=dev)
+        g_s.apply(want)
         got = rg.grid_fields_device(geom, f[:nf], m[:nf])
-        assert torch.equal(got.view(torch.int32), want.view(torch.int32)), nf
+        assert_same_to_rounding(got.view(nf, -1), want, scale)
+        g_t = CsrGridder(geom, f[0].numel(), nf, device=dev, tile=384)        # tile kernel over the same records
+        assert g_t.packed_stream
+        g_t.packed = g_s.packed
+        got_t = torch.empty_like(want)
+        g_t.apply(got_t)
+        assert torch.equal(got_t.view(torch.int32), want.view(torch.int32)), nf
+        del want, got, got_t
     five = rg.grid_fields_device(geom, f + f[:2], m + m[:2])                # 5 fields: a pass of 4 and a pass of 1
-    assert torch.equal(five[4].view(torch.int32), rg.grid_fields_device(c2["geom"], f[1:2], m[1:2])[0].view(torch.int32))
+    one = rg.grid_fields_device(geom, f[1:2], m[1:2])
+    assert torch.equal(five[4].view(torch.int32), one[0].view(torch.int32))
+    four = rg.grid_fields_device(geom, f + f[:1], m + m[:1])
+    assert torch.equal(five[:4].view(torch.int32), four.view(torch.int32))
+    del five, one, four
     assert geom.n_pairs() == std.n_pairs and geom.memory_usage_mb() < 0.75 * c2["geom"].memory_usage_mb()
     cress = rg.compute_grid_geometry(vol.gate_x, vol.gate_y, vol.gate_z, (2, 64, 64),
                                      ((1000.0, 2000.0), (-20e3, 20e3), (-20e3, 20e3)), str(tmp_path),
@@ -339,8 +397,9 @@ def test_c2_packed_only_layout(c2, tmp_path):
 
 
 def test_c2_pipeline_graph_with_compact_copy(c2):
-    """VolumePipeline(compact=True): the captured hipGraph (pack -> rg_csr_compact_apply_f32 -> COLMAX/argmax -> CAPPI)
-    replays to the same bits as the standard pipeline."""
+    """VolumePipeline(compact=True): the captured hipGraph (pack -> rg_csr_compact_apply_packed_f32 -> COLMAX/argmax ->
+    CAPPI) replays to the same bits every time and to the standard pipeline's values (float32 rounding: the compact
+    pass runs the row-wise kernel; the argmax level may differ where two levels tie to rounding)."""
     from radar_processor_amd.pipeline import VolumePipeline
     torch, geom, dev = c2["torch"], c2["geom"], c2["dev"]
     f, m = c2["fields"]["DBZH"], c2["masks"]["DBZH"]
@@ -352,10 +411,21 @@ def test_c2_pipeline_graph_with_compact_copy(c2):
         res = pipe.run([f], [m])                    # second call replays the graph
         torch.cuda.synchronize()
         outs.append([res[k].clone() for k in ("grid", "colmax", "argmax", "cappi")])
+        again = pipe.run([f], [m])
+        torch.cuda.synchronize()
+        for k, t in zip(("grid", "colmax", "argmax", "cappi"), outs[-1]):
+            assert torch.equal(torch.nan_to_num(again[k].float(), nan=-7e9), torch.nan_to_num(t.float(), nan=-7e9)), k
     assert len(outs[0]) == len(outs[1]) and len(outs[0]) > 0
-    for a, b in zip(outs[0], outs[1]):
-        assert torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a,
-                           b.view(torch.int32) if b.dtype == torch.float32 else b)
+    scale = float(f[torch.isfinite(f)].abs().max())
+    for k, a, b in zip(("grid", "colmax", "argmax", "cappi"), outs[0], outs[1]):
+        if k == "argmax":       # a different level only where the two levels tie to rounding
+            differ = a != b
+            assert float(differ.float().mean()) < 2e-3
+            grid_a, cmax_a = outs[0][0], outs[0][1]
+            at_b = grid_a[0].gather(0, b[0].clamp_min(0).long().unsqueeze(0))[0]
+            assert float((at_b - cmax_a[0]).abs()[differ[0]].max()) <= 2e-5 * scale
+        else:
+            assert_same_to_rounding(b, a, scale)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -385,7 +455,8 @@ def metric(tmp_path_factory):
 
 
 def _metric_grids(metric):
-    """K1 (reference-format CSR) and K1c (compact copy) grids of DBZH, computed once per module."""
+    """K1 (reference-format CSR) and K1c (compact copy, row-wise kernel over the packed records: what bench.py times)
+    grids of DBZH, computed once per module; also whether the tile kernel over the same records reproduced K1's bits."""
     if "k1" not in metric:
         from radar_processor_amd.gridding import CsrGridder
         torch, geom, dev, f, m = metric["torch"], metric["geom"], metric["dev"], metric["f"], metric["m"]
@@ -393,10 +464,17 @@ def _metric_grids(metric):
         g_c = CsrGridder(geom, f.numel(), 1, device=dev, compact=True)
         assert g_s.compact is None and g_c.compact is not None
         g_s.pack([f], [m]); g_c.pack([f], [m])
+        assert g_c.packed_stream
         k1 = torch.empty((1, g_s.n_vox), dtype=torch.float32, device=dev)
         k1c = torch.full_like(k1, -7.0)
         g_s.apply(k1); g_c.apply(k1c)
+        g_c.tile = 384                                 # the tile kernel over the same packed records
+        k1t = torch.full_like(k1, -7.0)
+        g_c.apply(k1t)
+        g_c.tile = 0
         torch.cuda.synchronize()
+        metric["tile_kernel_equals_k1"] = bool(torch.equal(k1.view(torch.int32), k1t.view(torch.int32)))
+        del k1t
         metric["k1"], metric["k1c"], metric["g_c"] = k1, k1c, g_c
     return metric["k1"], metric["k1c"]
 
@@ -421,12 +499,25 @@ def test_metric_int64_csr_structure(metric):
     assert float(w.min()) >= np.float32(np.exp(-4.0) + 1e-5) * (1 - 1e-6) and float(w.max()) <= 1.00002
 
 
-def test_metric_compact_equals_reference_format_bit_for_bit(metric):
-    """K1c (what bench.py times) == K1 (the reference's CSR format) on the full 8.3 G-pair geometry, bit for bit;
-    a constant field grids to the constant; the decoded compact copy reproduces gate_indices beyond offset 2^31."""
+def test_metric_compact_kernels_match_reference_format(metric):
+    """On the full 8.3 G-pair geometry: the tile kernel over the packed records == K1 (the reference's CSR format) bit
+    for bit; K1c's row-wise kernel (what bench.py times) == K1 to float32 rounding on every voxel and the same bits run
+    to run; a constant field grids to the constant; the decoded compact copy reproduces gate_indices beyond offset
+    2^31."""
     torch, geom, dev = metric["torch"], metric["geom"], metric["dev"]
     k1, k1c = _metric_grids(metric)
-    assert bool(torch.equal(k1.view(torch.int32), k1c.view(torch.int32)))
+    assert metric["tile_kernel_equals_k1"]
+    f = metric["f"]
+    scale = float(f[torch.isfinite(f) & (metric["m"] == 0)].abs().max())
+    assert bool(torch.equal(torch.isnan(k1), torch.isnan(k1c)))
+    err = (k1c - k1).abs() - 1e-5 * k1.abs()
+    assert float(torch.nan_to_num(err, nan=0.0).max()) <= 1e-5 * scale
+    del err
+    again = torch.full_like(k1c, -7.0)
+    metric["g_c"].pack([f], [metric["m"]])
+    metric["g_c"].apply(again)
+    assert bool(torch.equal(again.view(torch.int32), k1c.view(torch.int32)))
+    del again
     csr = geom.device_csr(dev)
     filled = torch.isfinite(k1[0])
     assert 0.55 < float(filled.float().mean()) < 0.8
@@ -452,10 +543,11 @@ def test_metric_compact_only_layout_with_int64_offsets(metric, tmp_path):
     """compute_grid_geometry(layout="compact") on the metric workload: the builder fills one slab of grid levels at a
     time into a scratch index buffer addressed by ABSOLUTE pair offsets (pointer shifts of up to 8.3e9 * 4 bytes), so
     this is the 64-bit path of the slab builder.  Row pointers and weights equal the standard build bit for bit, the
-    decoded indices equal its gate_indices beyond offset 2^31, and gridding gives the same bits."""
+    decoded indices equal its gate_indices beyond offset 2^31, and gridding (row-wise kernel over records packed from
+    the slab-built copy) gives the bits of the standard build's row-wise pass."""
     rg, torch, dev, vol, cfg = metric["rg"], metric["torch"], metric["dev"], metric["vol"], metric["cfg"]
     std = metric["geom"].device_csr(dev)
-    k1, _ = _metric_grids(metric)
+    _, k1c = _metric_grids(metric)
     geom = rg.compute_grid_geometry(vol.gate_x, vol.gate_y, vol.gate_z, cfg["grid_shape"], cfg["grid_limits"],
                                     str(tmp_path), layout="compact")
     csr = geom.device_csr(dev)
@@ -468,17 +560,18 @@ def test_metric_compact_only_layout_with_int64_offsets(metric, tmp_path):
         p0, p1 = int(std.indptr[r0]), int(std.indptr[r1])
         assert torch.equal(compact.decode(csr, r0, r1), std.gate_indices[p0:p1])
     got = rg.grid_fields_device(geom, [metric["f"]], [metric["m"]])
-    assert torch.equal(got.view(-1).view(torch.int32), k1.view(-1).view(torch.int32))
+    assert torch.equal(got.view(-1).view(torch.int32), k1c.view(-1).view(torch.int32))
     del got, geom, compact, csr
     torch.cuda.empty_cache()
 
 
 def test_metric_packed_only_layout_with_int64_offsets(metric, tmp_path):
     """layout="packed" on the metric workload: records packed slab by slab through shifted 64-bit pointers; decoded
-    indices and weights beyond pair offset 2^31 equal the standard build, the grid equals K1's bit for bit."""
+    indices and weights beyond pair offset 2^31 equal the standard build, the grid equals the standard build's row-wise
+    pass bit for bit."""
     rg, torch, dev, vol, cfg = metric["rg"], metric["torch"], metric["dev"], metric["vol"], metric["cfg"]
     std = metric["geom"].device_csr(dev)
-    k1, _ = _metric_grids(metric)
+    _, k1c = _metric_grids(metric)
     geom = rg.compute_grid_geometry(vol.gate_x, vol.gate_y, vol.gate_z, cfg["grid_shape"], cfg["grid_limits"],
                                     str(tmp_path), layout="packed")
     csr = geom.device_csr(dev)
@@ -491,7 +584,7 @@ def test_metric_packed_only_layout_with_int64_offsets(metric, tmp_path):
         assert torch.equal(compact.decode(csr, r0, r1), std.gate_indices[p0:p1])
         assert torch.equal(compact.decode_weights(csr, r0, r1).view(torch.int32), std.weights[p0:p1].view(torch.int32))
     got = rg.grid_fields_device(geom, [metric["f"]], [metric["m"]])
-    assert torch.equal(got.view(-1).view(torch.int32), k1.view(-1).view(torch.int32))
+    assert torch.equal(got.view(-1).view(torch.int32), k1c.view(-1).view(torch.int32))
     del got, geom, compact, csr
     torch.cuda.empty_cache()
 

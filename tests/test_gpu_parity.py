@@ -148,9 +148,10 @@ def test_apply_geometry_matches_reference(rg, name):
 
 @pytest.mark.parametrize("name", golden_names("g2_") + golden_names("g3_") + golden_names("g6_"))
 def test_compact_kernel_matches_reference(rg, name):
-    """rg_csr_compact_apply_f32 (the kernel bench.py times) fed the compact copy of the REFERENCE's CSR, against the
-    reference's gridded outputs directly -- single-field passes and the fused multi-field pass -- and bit for bit
-    against rg_csr_apply_f32 on the same CSR."""
+    """The compact kernels fed the compact copy of the REFERENCE's CSR, against the reference's gridded outputs directly
+    -- single-field passes and the fused multi-field pass: rg_csr_compact_apply_f32 (tile kernel; also bit for bit against
+    rg_csr_apply_f32 on the same CSR) and, where the reference's weights are codable (Barnes, nearest),
+    rg_csr_compact_apply_packed_f32's row-wise kernel -- the kernel bench.py times -- and its tile kernel."""
     import torch
     from radar_processor_amd.gridding import CsrGridder
     meta, ref = load_golden(name)
@@ -182,6 +183,18 @@ def test_compact_kernel_matches_reference(rg, name):
         assert torch.equal(got.view(torch.int32), std.view(torch.int32))
         for k, i in enumerate(group):
             _assert_grid_close(got[k].cpu().numpy().reshape(shape), ref[f"grid_{names[i]}"], _atol(*data_mask[i]))
+        if not compact.ensure_packed(g_c.csr):
+            assert meta["weighting"] == "cressman"               # weights down to 0: no 26-bit code
+            continue
+        g_c.packed_stream = True
+        for tile in (0, 384):                                    # row-wise kernel (default), tile kernel over the records
+            g_c.tile = tile
+            got.fill_(-5.0)
+            g_c.apply(got)
+            if tile == 384:
+                assert torch.equal(got.view(torch.int32), std.view(torch.int32))
+            for k, i in enumerate(group):
+                _assert_grid_close(got[k].cpu().numpy().reshape(shape), ref[f"grid_{names[i]}"], _atol(*data_mask[i]))
 
 
 def test_reference_grid_relative_error(rg):

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Row-wise fused kernel (rg_csr_compact_apply_packed_f32, tile >= 2000) against the tile kernel on one configuration:
+
+    python tools/exp_rowwise.py [--config C2|METRIC] [--fields 3] [--codes 2300,2308,2316] [--rounds 5]
+
+Prints one JSON object: per variant the median kernel time, TB/s in its own bytes and in SURVEY 8(d)'s, and the largest
+relative difference to the tile kernel's grids (the two sum in different orders)."""
+import argparse
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="C2")
+    ap.add_argument("--fields", default="3")
+    ap.add_argument("--codes", default="2300")
+    ap.add_argument("--rounds", type=int, default=5)
+    args = ap.parse_args()
+    import torch
+    import radar_processor_amd as rg
+    from radar_processor_amd import synthetic
+    from radar_processor_amd.gridding import CsrGridder
+    rg.load_library()
+    dev = torch.device("cuda", 0)
+    cfg = synthetic.CONFIGS[args.config]
+    names = ("DBZH", "ZDR", "RHOHV")
+    vol = synthetic.make_volume(cfg["n_elev"], cfg["n_az"], cfg["n_gates"], seed=0, fields=names)
+    with tempfile.TemporaryDirectory() as tmp:
+        geom = rg.compute_grid_geometry(vol.gate_x, vol.gate_y, vol.gate_z, cfg["grid_shape"], cfg["grid_limits"], tmp)
+    base_f = [torch.from_numpy(np.ascontiguousarray(np.ma.getdata(vol.fields[n]))).to(dev) for n in names]
+    base_m = [torch.from_numpy(np.ma.getmaskarray(vol.fields[n]).astype(np.uint8)).to(dev) for n in names]
+    qc = rg.device_gate_mask(base_f[2], "below", 0.8)
+    n_vox = int(np.prod(cfg["grid_shape"]))
+    compact = geom.device_compact(dev)
+    rec = {"config": args.config, "pairs": geom.n_pairs(), "window_cap": compact.window_cap, "runs": []}
+
+    def timed(fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); e1.synchronize()
+        return e0.elapsed_time(e1)
+
+    for nf in [int(x) for x in args.fields.split(",")]:
+        fl = [base_f[i % 3] for i in range(nf)]
+        ml = [base_m[i % 3] for i in range(nf)]
+        ref = CsrGridder(geom, fl[0].numel(), nf, device=dev, compact=True)
+        if ref.compact is None:
+            ref.compact, ref.window = compact, compact.window_for(nf)
+            ref.packed_stream = compact.ensure_packed(ref.csr)
+        ref.pack(fl, ml, qc if nf >= 3 else None)
+        out_ref = torch.empty((nf, n_vox), dtype=torch.float32, device=dev)
+        ref.apply(out_ref)
+        variants = [("tile", ref, out_ref)]
+        for code in [int(x) for x in args.codes.split(",")]:
+            g = CsrGridder(geom, fl[0].numel(), nf, device=dev, compact=True, tile=code)
+            g.compact, g.packed_stream = compact, True
+            g.window = compact.window_cap + 64          # sentinel entry included
+            g.packed = ref.packed
+            variants.append((f"row{code}", g, torch.empty_like(out_ref)))
+        times = {v[0]: [] for v in variants}
+        for r in range(args.rounds + 1):
+            for name, g, out in variants:
+                ms = timed(lambda: g.apply(out))
+                if r:
+                    times[name].append(ms)
+        a = out_ref.double()
+        for name, g, out in variants:
+            ms = float(np.median(times[name]))
+            b = out.double()
+            nan_same = bool(torch.equal(torch.isnan(a), torch.isnan(b)))
+            ok = ~torch.isnan(a)
+            rel = float(((a[ok] - b[ok]).abs() / a[ok].abs().clamp_min(1e-3)).max()) if nan_same else None
+            rec["runs"].append({"fields": nf, "kernel": name, "ms": round(ms, 4),
+                                "own_TBps": round(g.compact_bytes() / ms / 1e9, 3),
+                                "frac_8d": round(g.algorithmic_bytes() / ms / 1e9 / 8.0, 4),
+                                "nan_pattern_same": nan_same, "max_rel_diff_to_tile": rel,
+                                "bit_identical": bool(torch.equal(out.view(torch.int32), out_ref.view(torch.int32)))})
+    print(json.dumps(rec, indent=1))
+
+
+if __name__ == "__main__":
+    main()
