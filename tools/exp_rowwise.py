@@ -1,10 +1,14 @@
 #!/usr/bin/env python3
-"""Row-wise fused kernel (rg_csr_compact_apply_packed_f32, tile >= 2000) against the tile kernel on one configuration:
+"""Row-wise kernel (rg_csr_compact_apply_packed_f32) against the tile kernel over the same packed records, one configuration:
 
-    python tools/exp_rowwise.py [--config C2|METRIC] [--fields 3] [--codes 2300,2308,2316] [--rounds 5]
+    python tools/exp_rowwise.py [--config C2|METRIC] [--fields 1,3] [--codes 0,2004,2008,2074,2076] [--rounds 5]
 
-Prints one JSON object: per variant the median kernel time, TB/s in its own bytes and in SURVEY 8(d)'s, and the largest
-relative difference to the tile kernel's grids (the two sum in different orders)."""
+``--codes`` are ``tile`` arguments of the entry point: 0 = the shipped row-wise kernel, 2000 + h = a diagnostic lane split
+(h = 1..64 lanes per row, h = 70 + t: aim for t records per lane and row).  Prints one JSON object: per variant the median
+kernel time, TB/s in its own bytes and in SURVEY 8(d)'s, and the largest relative difference to the tile kernel's grids (the
+two sum in different orders).  profiles/r02_rowwise_sweep.json was produced with this script at the commit that
+introduced the kernel, when records per step, window entry size and the home of the row sums were still template
+parameters selectable through the code."""
 import argparse
 import json
 import os
@@ -20,7 +24,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="C2")
     ap.add_argument("--fields", default="3")
-    ap.add_argument("--codes", default="2300")
+    ap.add_argument("--codes", default="0,2004,2008,2016,2074,2076,2078")
     ap.add_argument("--rounds", type=int, default=5)
     args = ap.parse_args()
     import torch
@@ -53,6 +57,7 @@ def main():
         if ref.compact is None:
             ref.compact, ref.window = compact, compact.window_for(nf)
             ref.packed_stream = compact.ensure_packed(ref.csr)
+        ref.tile = 384                                   # the tile kernel over the packed records
         ref.pack(fl, ml, qc if nf >= 3 else None)
         out_ref = torch.empty((nf, n_vox), dtype=torch.float32, device=dev)
         ref.apply(out_ref)
@@ -60,7 +65,7 @@ def main():
         for code in [int(x) for x in args.codes.split(",")]:
             g = CsrGridder(geom, fl[0].numel(), nf, device=dev, compact=True, tile=code)
             g.compact, g.packed_stream = compact, True
-            g.window = compact.window_cap + 64          # sentinel entry included
+            g.window = compact.window_for(nf)
             g.packed = ref.packed
             variants.append((f"row{code}", g, torch.empty_like(out_ref)))
         times = {v[0]: [] for v in variants}
