@@ -166,8 +166,9 @@ def csr_apply(indptr, gate_indices, weights, field_values, field_mask, grid_shap
 
 def csr_apply_f64(indptr, gate_indices, weights, field_values, field_mask, grid_shape,
                   fill_value=np.nan) -> np.ndarray:
-    """Same contract as :func:`csr_apply` with float64 sums (float32 products kept): the yardstick used to
-    size the tolerance between the reference's float32 pairwise sums and the GPU's float64 accumulators."""
+    """Same contract as :func:`csr_apply` with float64 sums (float32 products kept): the yardstick used to size
+    the tolerance between different orders of float32 summation (the reference's pairwise ``reduceat``, the kernels'
+    tile / lane orders)."""
     indptr = np.asarray(indptr, dtype=np.int64)
     n_vox = int(np.prod(grid_shape))
     out = np.full(n_vox, fill_value, dtype="float32")
@@ -182,6 +183,85 @@ def csr_apply_f64(indptr, gate_indices, weights, field_values, field_mask, grid_
     ok = den > 0
     out[ok] = (num[ok] / den[ok]).astype(np.float32)
     return out.reshape(grid_shape)
+
+ROWWISE_TARGET = {1: 4, 2: 6, 3: 6, 4: 8}   # records per lane and row the row-wise kernel aims for, by field count
+
+
+def csr_apply_rowwise_order(indptr, gate_indices, weights, fields, masks, grid_shape, fill_value=np.nan,
+                            lanes_hint: int = 0) -> np.ndarray:
+    """The masked weighted mean of :func:`csr_apply` (interpolate.py:69-104) with the float32 additions performed in
+    exactly the order the row-wise kernel of ``rg_csr_compact_apply_packed_f32`` documents
+    (radar_processor_amd/csrc/rg_csr_compact.hip), so that the kernel can be checked BIT FOR BIT on small cases:
+
+    * a grid line of nx rows is cut into ceil(nx / 64) balanced segments; a segment's pairs are numbered from 0 and
+      grouped in records of three;
+    * per segment, L = 2^k lanes per row, k = ceil(log2(ceil(m / T))) capped at 6, m = span // (3 * rows) + 1 the mean
+      records per row and T = ROWWISE_TARGET[fields] (``lanes_hint``: 1..64 = that many lanes, 70 + t = target t);
+    * lane j of a row sums the row's pairs of records q0 + j, q0 + j + L, ... (q0 = first pair // 3) in ascending order,
+      one running float32 (sum w*v, sum w) per field, a masked gate adding +0 to both;
+    * the L lane sums are folded by an xor butterfly (x[i] += x[i ^ 1], then ^ 2, ^ 4, ...);
+    * value = float32(float64(sum w*v) / float64(sum w)) where sum w > 0, else ``fill_value``.
+
+    ``fields`` / ``masks``: sequences of F arrays [G] (mask True = excluded).  Returns float32 [F, nz, ny, nx].
+    Test infrastructure like the rest of this module; rows are looped in Python: small cases only."""
+    indptr = np.asarray(indptr, dtype=np.int64)
+    gate_indices = np.asarray(gate_indices)
+    w_all = np.asarray(weights, dtype=np.float32)
+    nz, ny, nx = (int(v) for v in grid_shape)
+    nf = len(fields)
+    vals = [np.asarray(f, dtype=np.float32) for f in fields]
+    excl = [np.zeros(vals[0].shape, dtype=bool) if m is None else np.asarray(m, dtype=bool) for m in masks]
+    out = np.full((nf, nz * ny * nx), fill_value, dtype=np.float32)
+    nsx = (nx + 63) // 64
+    seg_base, seg_extra = nx // nsx, nx % nsx
+    zero = np.float32(0.0)
+    for line in range(nz * ny):
+        x0 = 0
+        for sx in range(nsx):
+            nrows = seg_base + (1 if sx < seg_extra else 0)
+            r0 = line * nx + x0
+            x0 += nrows
+            seg_b = int(indptr[r0])
+            span = int(indptr[r0 + nrows]) - seg_b
+            if span == 0:
+                continue
+            if 0 < lanes_hint <= 64:
+                lgl = int(lanes_hint).bit_length() - 1
+            else:
+                target = lanes_hint - 70 if lanes_hint > 70 else ROWWISE_TARGET[nf]
+                need = (span // (3 * nrows) + 1 + target - 1) // target
+                lgl = 0 if need <= 1 else (need - 1).bit_length()
+            lanes = 1 << min(lgl, 6)
+            for r in range(r0, r0 + nrows):
+                ps, pe = int(indptr[r]), int(indptr[r + 1])
+                if pe == ps:
+                    continue
+                rs = ps - seg_b
+                o = np.arange(rs, pe - seg_b)                     # pair offsets in the segment
+                q = o // 3 - rs // 3                              # record number within the row
+                lane, slot = q % lanes, (q // lanes) * 3 + o % 3
+                width = int(slot.max()) + 1
+                g = gate_indices[ps:pe]
+                w = w_all[ps:pe]
+                for f in range(nf):
+                    good = ~excl[f][g]
+                    prod = np.where(good, w * vals[f][g], zero).astype(np.float32)   # float32 product, then the add
+                    wgt = np.where(good, w, zero).astype(np.float32)
+                    mp = np.zeros((lanes, width), dtype=np.float32)
+                    mw = np.zeros((lanes, width), dtype=np.float32)
+                    mp[lane, slot] = prod
+                    mw[lane, slot] = wgt
+                    with np.errstate(invalid="ignore", over="ignore"):
+                        sp = np.add.accumulate(mp, axis=1, dtype=np.float32)[:, -1]    # strictly sequential per lane
+                        sw = np.add.accumulate(mw, axis=1, dtype=np.float32)[:, -1]
+                        m = 1
+                        while m < lanes:
+                            partner = np.arange(lanes) ^ m
+                            sp, sw = (sp + sp[partner]).astype(np.float32), (sw + sw[partner]).astype(np.float32)
+                            m <<= 1
+                        if sw[0] > 0:
+                            out[f, r] = np.float32(np.float64(sp[0]) / np.float64(sw[0]))
+    return out.reshape(nf, nz, ny, nx)
 
 
 def merge_masks(field_data, extra_masks: Sequence[np.ndarray] = ()) -> Tuple[np.ndarray, np.ndarray]:

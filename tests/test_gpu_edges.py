@@ -485,6 +485,22 @@ def test_compact_and_packed_kernels_fuzz(rg, seed):
         got.fill_(9.0)
         g_r.apply(got, fill_value=-3.0)
         assert torch.equal(got.view(torch.int32), row.view(torch.int32)), ("row-wise, no window", nf, shape)
+        # ... and it is exactly the order the kernel documents: bit for bit against the oracle's restatement of that order,
+        # for the shipped lane split and for diagnostic ones (1 lane per row ... 64 lanes per row, other targets)
+        f_np = [t.cpu().numpy() for t in fields[:nf]]
+        m_np = [None if t is None else t.cpu().numpy().astype(bool) for t in masks[:nf]]
+        g_r.window = compact.window_for(nf)
+        for hint in ((0, 1, 8, 64, 71, 99) if nf in (1, 3) and seed < 4 else (0,)):
+            g_r.tile = 2000 + hint if hint else 0
+            got.fill_(9.0)
+            g_r.apply(got, fill_value=-3.0)
+            emu = oracle.csr_apply_rowwise_order(indptr, gidx, wts, f_np, m_np, shape, fill_value=-3.0,
+                                                 lanes_hint=hint).reshape(nf, n_vox)
+            got_np = got.cpu().numpy()
+            np.testing.assert_array_equal(np.isnan(got_np), np.isnan(emu))
+            live = ~np.isnan(emu)
+            assert np.array_equal(got_np.view(np.int32)[live], emu.view(np.int32)[live]), ("row-wise order", nf, hint, shape)
+        g_r.tile = 0
     # and against the float64 oracle (tolerance: float32 accumulation)
     data = fields[0].cpu().numpy()
     want64 = oracle.csr_apply_f64(indptr, gidx, wts, data, masks[0].cpu().numpy().astype(bool), shape, fill_value=-3.0)

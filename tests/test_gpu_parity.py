@@ -193,6 +193,14 @@ def test_compact_kernel_matches_reference(rg, name):
             g_c.apply(got)
             if tile == 384:
                 assert torch.equal(got.view(torch.int32), std.view(torch.int32))
+            else:       # the documented order of the row-wise kernel, restated by the oracle: bit for bit
+                emu = oracle.csr_apply_rowwise_order(ref["indptr"], reference_indices(name, meta, ref), ref["weights"],
+                                                     [data_mask[i][0] for i in group], [data_mask[i][1] for i in group],
+                                                     shape).reshape(nf, -1)
+                got_np = got.cpu().numpy()
+                np.testing.assert_array_equal(np.isnan(got_np), np.isnan(emu))
+                live = ~np.isnan(emu)
+                assert np.array_equal(got_np.view(np.int32)[live], emu.view(np.int32)[live])
             for k, i in enumerate(group):
                 _assert_grid_close(got[k].cpu().numpy().reshape(shape), ref[f"grid_{names[i]}"], _atol(*data_mask[i]))
 

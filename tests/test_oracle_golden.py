@@ -143,8 +143,8 @@ def test_csr_apply_matches_reference_grids(name):
 
 @pytest.mark.parametrize("name", golden_names("g3_c2_r150") + golden_names("g3_c2_r060"))
 def test_f64_yardstick_within_tolerance(name):
-    """The float64-accumulating variant (what the GPU computes) stays within the parity tolerance of the
-    reference's float32 pairwise sums: rtol 1e-5 with an absolute floor of 1e-5 * max|field|."""
+    """The float64-summing yardstick stays within the parity tolerance of the reference's float32 pairwise sums: rtol
+    1e-5 with an absolute floor of 1e-5 * max|field| (the kernels sum in float32 in their own orders)."""
     meta, ref = load_golden(name)
     vol = volume_for(meta)
     shape, _ = grid_spec(meta)
@@ -156,6 +156,49 @@ def test_f64_yardstick_within_tolerance(name):
         np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
         atol = 1e-5 * float(np.nanmax(np.abs(data[~mask])))
         np.testing.assert_allclose(got, want, rtol=1e-5, atol=atol, equal_nan=True)
+
+
+@pytest.mark.parametrize("name", golden_names("g2_") + golden_names("g3_c2_r150") + golden_names("g3_c2_r060")
+                         + golden_names("g6_"))
+def test_rowwise_order_restatement_is_the_reference_mean(name):
+    """oracle.csr_apply_rowwise_order -- the row-wise kernel's documented order of float32 additions, against which the
+    GPU tests check that kernel bit for bit -- is itself pinned here: on the REFERENCE's CSR it reproduces the reference's
+    grids (same voxels filled, rtol 1e-5 + 1e-5 * max|field|), fused fields equal single-field passes of the same lane
+    split bit for bit, and every lane split gives the same values to rounding."""
+    meta, ref = load_golden(name)
+    vol = volume_for(meta)
+    shape, _ = grid_spec(meta)
+    idx = reference_indices(name, meta, ref)
+    pairs = [oracle.merge_masks(vol.fields[f]) for f in meta["fields"]]
+    data, masks = [p[0] for p in pairs], [p[1] for p in pairs]
+    fused = oracle.csr_apply_rowwise_order(ref["indptr"], idx, ref["weights"], data, masks, shape)
+    for k, fname in enumerate(meta["fields"]):
+        want = ref[f"grid_{fname}"]
+        atol = 1e-5 * float(np.nanmax(np.abs(data[k][~masks[k]])))
+        np.testing.assert_array_equal(np.isnan(fused[k]), np.isnan(want))
+        np.testing.assert_allclose(fused[k], want, rtol=1e-5, atol=atol, equal_nan=True)
+        hint = 70 + oracle.ROWWISE_TARGET[len(data)]          # a single-field pass with the fused pass's lane split
+        single = oracle.csr_apply_rowwise_order(ref["indptr"], idx, ref["weights"], data[k:k + 1], masks[k:k + 1], shape,
+                                                lanes_hint=hint)[0]
+        np.testing.assert_array_equal(single, fused[k])
+        for lanes in (1, 64):
+            other = oracle.csr_apply_rowwise_order(ref["indptr"], idx, ref["weights"], data[k:k + 1], masks[k:k + 1],
+                                                   shape, lanes_hint=lanes)[0]
+            np.testing.assert_allclose(other, want, rtol=1e-5, atol=atol, equal_nan=True)
+
+
+def test_rowwise_order_restatement_known_answers():
+    """The reference's unit-test answers (test_radar_grid_interpolate.py:75-93, :236-277, :116-153) through the restatement."""
+    def run(indptr, idx, w, values, fill=np.nan):
+        values = np.asarray(values, dtype=np.float32)
+        return oracle.csr_apply_rowwise_order(np.asarray(indptr), np.asarray(idx, dtype=np.int32),
+                                              np.asarray(w, dtype=np.float32), [values], [~np.isfinite(values)], (1, 1, 1),
+                                              fill)[0, 0, 0, 0]
+    np.testing.assert_almost_equal(run([0, 2], [0, 1], [0.3, 0.7], [10.0, 20.0]), 17.0, decimal=5)
+    np.testing.assert_almost_equal(run([0, 3], [0, 1, 2], [0.2, 0.5, 0.3], [10.0, 20.0, 30.0]), 21.0, decimal=5)
+    np.testing.assert_almost_equal(run([0, 3], [0, 1, 2], [0.3, 0.4, 0.3], [10.0, np.nan, 30.0]), 20.0, decimal=5)
+    assert run([0, 0], [], [], [1.0], fill=-9999.0) == np.float32(-9999.0)
+    assert np.isnan(run([0, 2], [0, 1], [0.5, 0.5], [np.nan, np.nan]))
 
 
 def _product_checks(prefix, grid, z_limits, ref):
