@@ -414,7 +414,6 @@ class GridGeometry:
         self._dev = None
         self.__dict__.pop("_compact", None)
         self.__dict__.pop("_gridders", None)
-        self.__dict__.pop("_passes", None)
 
     @property
     def indptr(self) -> np.ndarray:

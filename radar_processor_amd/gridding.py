@@ -12,9 +12,11 @@ Two layers:
 
 All fields handed to one call are gridded by ONE pass over the CSR (the reference re-reads the CSR per field,
 interpolate.py:137-140): the mask of every field is folded into its values and the fields are interleaved
-gate-major, so each (voxel, gate) pair costs a single gather.  Passes over a large geometry switch, from the second use
-of that geometry on, to a compact device copy of the CSR (``rg_csr_compact_apply_f32``: 16-bit positions in a per-chunk
-gate dictionary, the chunk's field values staged in LDS) -- identical results, 25-40 % less time.
+gate-major, so each (voxel, gate) pair costs a single gather.  Passes over a large geometry (50 M pairs and up) run
+through a compact device copy of the CSR, built the first time the geometry grids something (16-bit positions in a
+per-chunk gate dictionary, the chunk's field values staged in LDS, positions and weights packed three pairs to a 16-byte
+record where the weights allow: ``rg_csr_compact_apply_packed_f32`` / ``rg_csr_compact_apply_f32``) -- the same values to
+float32 rounding, 35-50 % less time.
 """
 from __future__ import annotations
 
@@ -209,17 +211,16 @@ _COMPACT_MAX_FALLBACK = 0.02        # share of pairs allowed on the per-pair pat
 
 
 def _use_compact(geometry: GridGeometry, dev) -> bool:
-    """Policy of ``grid_fields_device`` / ``apply_geometry``: the compact copy of the CSR costs a one-time conversion
-    (about 15 ms per 1e9 pairs) and 2.2 bytes per pair of HBM, so it is built the SECOND time a geometry grids
-    something, when the geometry is large enough to matter and the memory is there; once built it is always used.
-    ``GridGeometry.device_compact()`` builds it explicitly ahead of time."""
+    """Policy of ``grid_fields_device`` / ``apply_geometry``: a geometry large enough to matter grids through the compact
+    copy of its CSR from its FIRST pass on, provided the memory is there -- the one-time conversion costs about as much
+    as building the geometry did (15 ms per 1e9 pairs for the copy, as much again for the packed records), and deciding by
+    size alone means that every pass of a geometry runs the same kernel and returns the same bits.  Once built the copy is
+    always used.  ``GridGeometry.device_compact()`` builds it explicitly ahead of time."""
     cached = getattr(geometry, "_compact", None)
     if cached is not None and cached[0] is geometry.device_csr(dev):
         return cached[1] is not None
-    uses = getattr(geometry, "_passes", 0) + 1
-    geometry._passes = uses
     n_pairs = geometry.device_csr(dev).n_pairs
-    if uses < 2 or n_pairs < _COMPACT_MIN_PAIRS:
+    if n_pairs < _COMPACT_MIN_PAIRS:
         return False
     free_b, _ = _native.torch_mod().cuda.mem_get_info(dev)
     return free_b > 3.2 * n_pairs + (8 << 30)

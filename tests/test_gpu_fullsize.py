@@ -277,26 +277,29 @@ def test_c2_compact_csr_is_bit_identical(c2):
         assert bool(torch.equal(again.view(torch.int32), got_r.view(torch.int32)))
 
 
-def test_c2_passes_switch_to_the_compact_copy(c2):
-    """gridding._use_compact: the first pass of a geometry runs the standard kernel, the second builds the compact copy
-    and every later pass -- single- or multi-field -- uses it (row-wise kernel over the packed records: the same values
-    to float32 rounding, the same bits from then on)."""
+def test_c2_passes_use_the_compact_copy_from_the_first(c2):
+    """gridding._use_compact: a geometry of config 2's size grids through the compact copy from its first pass on --
+    single- or multi-field, row-wise kernel over the packed records -- so every pass of the geometry returns the same bits;
+    they equal the standard kernel's to float32 rounding."""
     rg, torch, dev = c2["rg"], c2["torch"], c2["dev"]
     from radar_processor_amd.grid_geometry import GridGeometry
+    from radar_processor_amd.gridding import CsrGridder
     geom = GridGeometry.from_device(c2["geom"].grid_shape, c2["geom"].grid_limits, c2["geom"].device_csr(dev), 17000.0)
     f, m = c2["fields"]["ZDR"], c2["masks"]["ZDR"]
-    first = rg.grid_fields_device(geom, [f], [m]).clone()
     assert getattr(geom, "_compact", None) is None
+    first = rg.grid_fields_device(geom, [f], [m]).clone()
+    assert geom._compact is not None and geom._compact[1] is not None and geom._compact[1].rec is not None
     two_a = rg.grid_fields_device(geom, [f, c2["fields"]["DBZH"]], [m, None]).clone()
-    assert geom._compact is not None and geom._compact[1] is not None
-    second = rg.grid_fields_device(geom, [f], [m]).clone()
-    two_b = rg.grid_fields_device(c2["geom"], [f, c2["fields"]["DBZH"]], [m, None])     # standard kernel (first use)
-    scale = float(c2["fields"]["DBZH"][torch.isfinite(c2["fields"]["DBZH"])].abs().max())
-    assert_same_to_rounding(second, first, scale)
-    assert_same_to_rounding(two_a, two_b, scale)
+    second = rg.grid_fields_device(geom, [f], [m])
+    assert torch.equal(first.view(torch.int32), second.view(torch.int32))
     assert len(geom._gridders) >= 2                                 # gridders (and staging buffers) are reused
-    third = rg.grid_fields_device(geom, [f], [m])
-    assert torch.equal(second.view(torch.int32), third.view(torch.int32))
+    g_s = CsrGridder(geom, f.numel(), 2, device=dev)                # the standard kernel on the same inputs
+    g_s.pack([f, c2["fields"]["DBZH"]], [m, None])
+    std = torch.empty((2, g_s.n_vox), dtype=torch.float32, device=dev)
+    g_s.apply(std)
+    scale = float(c2["fields"]["DBZH"][torch.isfinite(c2["fields"]["DBZH"])].abs().max())
+    assert_same_to_rounding(two_a.view(2, -1), std, scale)
+    assert_same_to_rounding(first.view(1, -1), std[:1], scale)
 
 
 def test_c2_compact_only_layout(c2, tmp_path):
