@@ -65,7 +65,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-compact", action="store_true",
                     help="csr mode: run the standard 8-byte-per-pair kernel instead of the compact device copy of the "
-                         "CSR (identical results)")
+                         "CSR (the same values to float32 rounding)")
     ap.add_argument("--tile-kernel", action="store_true",
                     help="csr mode, A/B: run the tile kernel over the packed records (bit-identical to the standard kernel) "
                          "instead of the row-wise kernel")

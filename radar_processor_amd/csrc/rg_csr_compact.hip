@@ -1,4 +1,9 @@
-// K1c  csr_apply over a COMPACT device copy of the CSR (same results as rg_csr_apply_f32, bit for bit).
+// K1c  csr_apply over a COMPACT device copy of the CSR.  Two families of kernels share the chunk layout, the
+// dictionaries and the LDS field window described here:
+//   * the TILE kernels (rg_csr_compact_apply_f32; rg_csr_compact_apply_packed_f32 with tile = 384), first half of this
+//     file: rg_csr_apply_f32's pipeline minus its gather stage -- the same results as rg_csr_apply_f32, bit for bit;
+//   * the ROW-WISE kernel (rg_csr_compact_apply_packed_f32, tile = 0; second half): no LDS tile at all, the default for
+//     passes of 1-4 fields -- the same results to float32 rounding, in an order of its own.
 //
 // The reference's CSR (radar_grid/geometry.py:46-52) stores a 32-bit gate index per pair, and K1 pays for it twice:
 // 4 of the 8 streamed bytes per pair, and one global gather per pair (F values wide), which the texture-address path
@@ -18,13 +23,13 @@
 //   to cover all but a handful of chunks -- those next to the radar, where every ray converges); a chunk with more
 //   distinct gates gathers per pair through its dictionary instead.
 //
-// Pair order, weights, tiles and the float32 arithmetic are those of rg_csr_apply_f32 (same segments, same tiles, same
-// products, same dynamic row phase), so the two kernels agree exactly for every field count; the compact copy is
-// derived from the standard CSR on the device (grid_geometry.CompactCSR) and the standard arrays stay the
+// Tile kernels: pair order, weights, tiles and the float32 arithmetic are those of rg_csr_apply_f32 (same segments, same
+// tiles, same products, same dynamic row phase), so they agree with it exactly for every field count.  The compact copy
+// is derived from the standard CSR on the device (grid_geometry.CompactCSR) and the standard arrays stay the
 // interchange format.
 //
 // Roofline: HBM.  Bytes per launch = 6*P + 4*D + sizeof(indptr)*(V+1) + 8*(C+1) + F*(5*G + 4*V)  with D = total
-// dictionary entries, C = chunks.
+// dictionary entries, C = chunks; with the packed records (see rg_csr_compact_pack) 16*R + 8*(S+1) replace 6*P.
 #include <type_traits>
 
 #include "rg_common.hpp"
