@@ -15,6 +15,7 @@ multi-millisecond gridding kernel.
 from __future__ import annotations
 
 import os
+import contextlib
 from typing import Callable, Dict, Iterable, List, Optional, Sequence
 
 import numpy as np
@@ -104,9 +105,11 @@ def gather_results(local: Dict[int, object], n_items: int, dst: int = 0, group=N
 
 
 class VolumeBatch:
-    """Grids this rank's shard of a batch of volumes through one shared geometry, fusing up to 8 field-volumes
-    into each pass (the CSR -- or, for the CSR-free gridder, the candidate search -- is the dominant cost, so it is
-    paid once for the whole group).
+    """Grids this rank's shard of a batch of volumes through one shared geometry, fusing up to 4 (CSR path) or 8
+    (CSR-free path) field-volumes into each pass (the CSR -- or, for the CSR-free gridder, the candidate search -- is the
+    dominant cost, so it is paid once for the whole group).  Inputs that live in host memory are uploaded one group
+    ahead on a copy stream, so that the upload of group g+1 overlaps the gridding of group g (page-locked tensors
+    copy asynchronously; NumPy arrays and pageable tensors still work, synchronously).
 
     ``geometry``: a :class:`GridGeometry` (CSR path, ``rg_csr_apply_f32``) or a :class:`RoiSearch` (fused path,
     ``rg_roi_grid_f32``; measured faster than the CSR path as soon as 3 or more field-volumes share a pass).
@@ -124,9 +127,10 @@ class VolumeBatch:
         self.dev = geometry.dev if self.fused else _native.canonical_device(device)
         if not 1 <= len(self.field_names) <= _native.RG_MAX_FIELDS:
             raise ValueError("1..8 fields per volume")
-        # measured on the bench grid (ms per fused pass, rg_csr_apply_f32): 1 field-volume 13.1 (9.5 through the compact
-        # copy), 2: 14.9 (13.0), 3: 18.8, 4: 20.7, 8: 55.1 -- four field-volumes per pass is the sweet spot (5.2 ms
-        # each); the CSR-free gridder keeps gaining up to 8 because it shares the whole neighbour search
+        # measured on the bench grid (ms per fused pass): row-wise kernel over the packed records 7.9 / 8.7 / 10.1 / 11.4
+        # for 1-4 field-volumes (2.9 ms each at four; it takes at most four), rg_csr_apply_f32 13.1 / 14.9 / 18.8 / 20.7
+        # and 55.1 for eight -- four per pass either way; the CSR-free gridder keeps gaining up to 8 because it shares
+        # the whole neighbour search
         cap = _native.RG_MAX_FIELDS if self.fused else min(4, _native.RG_MAX_FIELDS)
         self.volumes_per_pass = max(1, cap // len(self.field_names))
 
@@ -137,6 +141,46 @@ class VolumeBatch:
         if not type(a).__module__.startswith("torch"):
             a = torch.from_numpy(np.ascontiguousarray(a))
         return a.to(device=self.dev, dtype=dtype).contiguous()
+
+    def _stage(self, volumes, group, slot_set, copy_stream):
+        """Device tensors of one group's fields and masks.  Inputs already on the device pass through; anything that has
+        to cross PCIe is copied on ``copy_stream`` into one of two persistent sets of staging buffers (no allocation per
+        step, nothing for the caching allocator to keep alive across streams).  Returns ``(fields, masks, event or
+        None)`` -- the event marks the end of the copies."""
+        import torch
+
+        def on_device(a):
+            return type(a).__module__.startswith("torch") and a.is_cuda
+
+        host = [a for b in group for name in self.field_names for a in volumes[b][name] if a is not None and not on_device(a)]
+        if not host:
+            fields = [self._to_dev(volumes[b][name][0], torch.float32) for b in group for name in self.field_names]
+            masks = [self._to_dev(volumes[b][name][1], torch.uint8) for b in group for name in self.field_names]
+            return fields, masks, None
+        n_gates = int(np.prod(host[0].shape))
+        slots = self.volumes_per_pass * len(self.field_names)
+        if getattr(self, "_staging", None) is None or self._staging[0][0].shape != (slots, n_gates):
+            self._staging = [(torch.empty((slots, n_gates), dtype=torch.float32, device=self.dev),
+                              torch.empty((slots, n_gates), dtype=torch.uint8, device=self.dev)) for _ in range(2)]
+            self._staging_free = [None, None]
+        vals, msks = self._staging[slot_set]
+        fields, masks = [], []
+        with torch.cuda.stream(copy_stream):
+            if self._staging_free[slot_set] is not None:      # the pass that last read this set must have finished
+                copy_stream.wait_event(self._staging_free[slot_set])
+            k = 0
+            for b in group:
+                for name in self.field_names:
+                    for a, buf, out in zip(volumes[b][name], (vals[k], msks[k]), (fields, masks)):
+                        if a is None or on_device(a):
+                            out.append(a if a is None else self._to_dev(a, buf.dtype))
+                            continue
+                        src = a if type(a).__module__.startswith("torch") else torch.from_numpy(np.ascontiguousarray(a))
+                        buf.copy_(src.reshape(-1), non_blocking=True)
+                        out.append(buf)
+                    k += 1
+            event = copy_stream.record_event()
+        return fields, masks, event
 
     def grid_shard(self, volumes: Sequence[dict], products: Optional[Callable] = None, rank=None,
                    world_size=None, events: Optional[list] = None) -> Dict[int, object]:
@@ -151,14 +195,20 @@ class VolumeBatch:
         mine = shard_indices(len(volumes), rank, world_size)
         out: Dict[int, object] = {}
         n_f = len(self.field_names)
-        for g0 in range(0, len(mine), self.volumes_per_pass):
-            group = mine[g0:g0 + self.volumes_per_pass]
-            fields, masks = [], []
-            for b in group:
-                for name in self.field_names:
-                    values, mask = volumes[b][name]
-                    fields.append(self._to_dev(values, torch.float32))
-                    masks.append(self._to_dev(mask, torch.uint8))
+        groups = [mine[g0:g0 + self.volumes_per_pass] for g0 in range(0, len(mine), self.volumes_per_pass)]
+        if not groups:
+            return out
+        with torch.cuda.device(self.dev):
+            compute = torch.cuda.current_stream()
+            copy_stream = self._copy_stream = getattr(self, "_copy_stream", None) or torch.cuda.Stream()
+            staged = self._stage(volumes, groups[0], 0, copy_stream)
+        for gi, group in enumerate(groups):
+            fields, masks, ready = staged
+            if ready is not None:
+                compute.wait_event(ready)
+            if gi + 1 < len(groups):                    # the next group's upload runs while this group is gridded
+                with torch.cuda.device(self.dev):
+                    staged = self._stage(volumes, groups[gi + 1], (gi + 1) & 1, copy_stream)
             if events is not None:
                 pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 pair[0].record()
@@ -169,6 +219,8 @@ class VolumeBatch:
             if events is not None:
                 pair[1].record()
                 events.append(pair)
+            if ready is not None:                       # this group's staging set may be overwritten once the pass is done
+                self._staging_free[gi & 1] = compute.record_event()
             for i, b in enumerate(group):
                 g = grids[i * n_f:(i + 1) * n_f]
                 out[b] = products(g) if products is not None else g
