@@ -210,41 +210,66 @@ def test_reference_grid_relative_error(rg):
     the comparison above carries an absolute floor (1e-5 * max|field|) for weighted means that cancel to ~0.  This test
     justifies it: over every reference fixture grid, per field, it measures the worst RELATIVE error on the voxels whose
     magnitude is above 1e-3 * max|field| and asserts <= 1e-5 there with NO absolute term, and it counts the voxels of
-    the whole grid that only pass thanks to the floor.  The numbers are written to gpurun_out/parity_relerr.json."""
+    the whole grid that only pass thanks to the floor -- for the standard kernel (``apply_geometry`` on these small
+    geometries) and for the row-wise kernel over the packed records of the same CSR (what large geometries run).  The
+    numbers are written to gpurun_out/parity_relerr.json."""
     import json
     import os
-    worst = {}
-    total = dict(voxels=0, significant=0, needed_floor=0)
-    for name in golden_names("g2_") + golden_names("g3_") + golden_names("g6_"):
-        meta, ref = load_golden(name)
-        vol = volume_for(meta)
-        geom = _ref_geometry(rg, name, meta, ref)
-        radar = vol.as_radar()
-        for fname in meta["fields"]:
-            data, mask = oracle.merge_masks(vol.fields[fname])
-            scale = _atol(data, mask) / RTOL                    # max |field| over the unmasked finite gates
-            got = rg.apply_geometry(geom, rg.get_field_data(radar, fname))
-            want = ref[f"grid_{fname}"]
-            filled = np.isfinite(want)
-            np.testing.assert_array_equal(np.isfinite(got), filled)
-            err = np.abs(got[filled].astype(np.float64) - want[filled].astype(np.float64))
-            mag = np.abs(want[filled].astype(np.float64))
-            sig = mag > 1e-3 * scale
-            rel = float((err[sig] / mag[sig]).max()) if sig.any() else 0.0
-            needed = int((err > RTOL * mag).sum())              # voxels that would fail a purely relative comparison
-            rec = worst.setdefault(fname, dict(max_rel_significant=0.0, needed_floor=0, voxels=0, max_abs_over_scale=0.0))
-            rec["max_rel_significant"] = max(rec["max_rel_significant"], rel)
-            rec["needed_floor"] += needed
-            rec["voxels"] += int(filled.sum())
-            rec["max_abs_over_scale"] = max(rec["max_abs_over_scale"], float(err.max() / scale) if err.size else 0.0)
-            total["voxels"] += int(filled.sum()); total["significant"] += int(sig.sum()); total["needed_floor"] += needed
-            assert rel <= RTOL, (name, fname, rel)              # no absolute floor here
+    import torch
+    from radar_processor_amd.gridding import CsrGridder
+    dev = torch.device("cuda", 0)
+    report = {}
+    for kernel in ("standard", "rowwise"):
+        worst = {}
+        total = dict(voxels=0, significant=0, needed_floor=0)
+        for name in golden_names("g2_") + golden_names("g3_") + golden_names("g6_"):
+            meta, ref = load_golden(name)
+            vol = volume_for(meta)
+            geom = _ref_geometry(rg, name, meta, ref)
+            radar = vol.as_radar()
+            shape = tuple(meta["grid_shape"])
+            gridder = None
+            if kernel == "rowwise":
+                if geom.device_csr(dev).n_pairs == 0 or meta["weighting"] == "cressman":
+                    continue                                    # nothing to grid / weights not codable
+                compact = geom.device_compact(dev)
+                gridder = CsrGridder(geom, vol.n_total_gates, 1, device=dev)
+                gridder.compact, gridder.window = compact, compact.window_for(1)
+                gridder.packed_stream = compact.ensure_packed(gridder.csr)
+                assert gridder.packed_stream
+            for fname in meta["fields"]:
+                data, mask = oracle.merge_masks(vol.fields[fname])
+                scale = _atol(data, mask) / RTOL                    # max |field| over the unmasked finite gates
+                if gridder is None:
+                    got = rg.apply_geometry(geom, rg.get_field_data(radar, fname))
+                else:
+                    gridder.pack([torch.from_numpy(np.ascontiguousarray(data)).to(dev)],
+                                 [torch.from_numpy(mask.astype(np.uint8)).to(dev)])
+                    out = torch.empty((1, gridder.n_vox), dtype=torch.float32, device=dev)
+                    gridder.apply(out)
+                    got = out.cpu().numpy().reshape(shape)
+                want = ref[f"grid_{fname}"]
+                filled = np.isfinite(want)
+                np.testing.assert_array_equal(np.isfinite(got), filled)
+                err = np.abs(got[filled].astype(np.float64) - want[filled].astype(np.float64))
+                mag = np.abs(want[filled].astype(np.float64))
+                sig = mag > 1e-3 * scale
+                rel = float((err[sig] / mag[sig]).max()) if sig.any() else 0.0
+                needed = int((err > RTOL * mag).sum())              # voxels that would fail a purely relative comparison
+                rec = worst.setdefault(fname, dict(max_rel_significant=0.0, needed_floor=0, voxels=0, max_abs_over_scale=0.0))
+                rec["max_rel_significant"] = max(rec["max_rel_significant"], rel)
+                rec["needed_floor"] += needed
+                rec["voxels"] += int(filled.sum())
+                rec["max_abs_over_scale"] = max(rec["max_abs_over_scale"], float(err.max() / scale) if err.size else 0.0)
+                total["voxels"] += int(filled.sum()); total["significant"] += int(sig.sum()); total["needed_floor"] += needed
+                assert rel <= RTOL, (kernel, name, fname, rel)      # no absolute floor here
+        report[kernel] = dict(per_field=worst, total=total)
+        # the floor is a rarity, not a crutch: at most one filled voxel in a thousand needs it
+        assert total["needed_floor"] <= 1e-3 * total["voxels"], (kernel, total)
     os.makedirs("gpurun_out", exist_ok=True)
     with open(os.path.join("gpurun_out", "parity_relerr.json"), "w") as fh:
-        json.dump(dict(per_field=worst, total=total), fh, indent=1)
-    print("parity_relerr", json.dumps(dict(per_field=worst, total=total)))
-    # the floor is a rarity, not a crutch: at most one filled voxel in a thousand needs it
-    assert total["needed_floor"] <= 1e-3 * total["voxels"], total
+        json.dump(report, fh, indent=1)
+    print("parity_relerr", json.dumps(report))
 
 
 @pytest.mark.parametrize("n_fields", [1, 2, 3, 4, 5, 8, 11])
