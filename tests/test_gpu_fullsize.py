@@ -399,22 +399,26 @@ def test_c2_packed_only_layout(c2, tmp_path):
     assert cress.device_csr(dev).weights is not None and cress.device_csr(dev).gate_indices is None
 
 
-def test_c2_pipeline_graph_with_compact_copy(c2):
-    """VolumePipeline(compact=True): the captured hipGraph (pack -> rg_csr_compact_apply_packed_f32 -> COLMAX/argmax ->
-    CAPPI) replays to the same bits every time and to the standard pipeline's values (float32 rounding: the compact
-    pass runs the row-wise kernel; the argmax level may differ where two levels tie to rounding)."""
+@pytest.mark.parametrize("n_fields", [1, 3])
+def test_c2_pipeline_graph_with_compact_copy(c2, n_fields):
+    """VolumePipeline(compact=True), one field and config 3's three: the captured hipGraph (pack ->
+    rg_csr_compact_apply_packed_f32 -> COLMAX/argmax -> CAPPI) replays to the same bits every time and to the standard
+    pipeline's values (float32 rounding: the compact pass runs the row-wise kernel; the argmax level may differ where two
+    levels tie to rounding)."""
     from radar_processor_amd.pipeline import VolumePipeline
     torch, geom, dev = c2["torch"], c2["geom"], c2["dev"]
+    names = ["DBZH", "ZDR", "RHOHV"][:n_fields]
     f, m = c2["fields"]["DBZH"], c2["masks"]["DBZH"]
+    fl, ml = [c2["fields"][n] for n in names], [c2["masks"][n] for n in names]
     outs = []
     for compact in (False, True):
-        pipe = VolumePipeline(geom, f.numel(), 1, compact=compact, device=dev)
-        assert (pipe.gridder.compact is not None) == compact
-        pipe.run([f], [m])
-        res = pipe.run([f], [m])                    # second call replays the graph
+        pipe = VolumePipeline(geom, f.numel(), n_fields, compact=compact, device=dev)
+        assert (pipe.gridder.compact is not None) == compact and pipe.gridder.packed_stream == compact
+        pipe.run(fl, ml)
+        res = pipe.run(fl, ml)                      # second call replays the graph
         torch.cuda.synchronize()
         outs.append([res[k].clone() for k in ("grid", "colmax", "argmax", "cappi")])
-        again = pipe.run([f], [m])
+        again = pipe.run(fl, ml)
         torch.cuda.synchronize()
         for k, t in zip(("grid", "colmax", "argmax", "cappi"), outs[-1]):
             assert torch.equal(torch.nan_to_num(again[k].float(), nan=-7e9), torch.nan_to_num(t.float(), nan=-7e9)), k
