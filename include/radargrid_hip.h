@@ -331,8 +331,9 @@ int rg_csr_compact_apply_f32(const void* indptr, int32_t indptr_is_i64, const ui
 /* Packed pair stream of the compact copy: positions and weights of three consecutive pairs of a segment in one 16-byte
  * record -- 5.33 bytes per pair instead of 6, streamed with one 16-byte load per lane.
  *   record = [w0:26 | p2 bits 0-5] [w1:26 | p2 bits 6-11] [w2:26 | p2 bits 12-15] [p0:16 | p1:16]   (4 x uint32)
- *   weight code = float32 bits of the weight - w_base; the caller guarantees that every code fits 26 bits (all weights
- *   positive and within 8 binades of w_base >> 23), which makes the coding lossless.
+ *   weight code = float32 bits of the weight - w_base; w_base has its low 26 bits clear (an exponent that is a multiple of
+ *   8, shifted left by 23), so adding it back is an OR; the caller guarantees that every code fits 26 bits (all weights
+ *   positive, exponents w_base >> 23 .. (w_base >> 23) + 7), which makes the coding lossless.
  * Segments (the <= 64 rows one wavefront owns) are numbered line-major, seg = line * ceil(line_len / 64) + sx; segment
  * seg owns records rec_ptr[seg] .. rec_ptr[seg+1], ceil(pairs / 3) of them and fewer than 2^27 (rec_ptr has segments + 1
  * entries, built by the caller).  rg_csr_compact_pack fills `records` from local_idx + weights (error_flag: 1 = rec_ptr

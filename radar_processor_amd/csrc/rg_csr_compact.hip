@@ -575,7 +575,9 @@ extern "C" int rg_csr_compact_pack(const void* indptr, int32_t indptr_is_i64, co
 //   KPRE   records per lane and step;   kTarget  records per lane and row L aims for;
 //   kNarrow  12-byte window entries for three fields (three 4-byte LDS reads per pair instead of one 16-byte read,
 //            but a quarter less LDS per workgroup);
-//   kRegs    the row sums travel to lane == row by shuffle and wait in registers instead of an LDS array.
+//   kRegs    the row sums travel to lane == row by shuffle and wait in registers instead of an LDS array;
+//   one field: the window holds (value, 1) per gate, (0, 0) where it is excluded, and a pair contributes w * (v', m) --
+//            the same float32 values as selecting on the sentinel, in packed multiply / add instructions.
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
 
@@ -594,6 +596,10 @@ __global__ __launch_bounds__(64 * kH) void csr_compact_rowwise_kernel(
   using Cfg = RowwiseConfig<NF>;
   constexpr int KPRE = Cfg::kpre;
   constexpr bool kNarrow = Cfg::narrow, kRegs = Cfg::regs;
+  // one field: the window holds (v', m) = (value, 1) of a gate, (0, 0) where it is excluded, so that a pair contributes
+  // w * (v', m) -- the same float32 values as selecting on the EXCLUDED sentinel (w * 0 = +0, w * 1 = w) in two packed
+  // instructions instead of a compare, two selects, a product and two adds
+  constexpr bool kPremask = NF == 1;
   extern __shared__ __attribute__((aligned(16))) float window[];   // window_cap + 1 entries of STRIDE (kNarrow: 3) floats
   __shared__ f32x2 rowacc_all[kRegs ? 1 : kH][kRegs ? 2 : 64 * NF];
   const int lane = threadIdx.x & 63;
@@ -670,6 +676,9 @@ __global__ __launch_bounds__(64 * kH) void csr_compact_rowwise_kernel(
       }
       if constexpr (kNarrow) {
         window[i * 3] = v[0]; window[i * 3 + 1] = v[1]; window[i * 3 + 2] = v[2];
+      } else if constexpr (kPremask) {
+        const bool good = rg::f32_bits(v[0]) != RG_EXCLUDED_BITS;
+        reinterpret_cast<f32x2*>(window)[i] = good ? (f32x2){v[0], 1.0f} : (f32x2){0.0f, 0.0f};
       } else if constexpr (STRIDE == 1) {
         window[i] = v[0];
       } else if constexpr (STRIDE == 2) {
@@ -728,24 +737,32 @@ __global__ __launch_bounds__(64 * kH) void csr_compact_rowwise_kernel(
     for (int f = 0; f < NF; ++f) ap[f] = aw[f] = 0.0f;
     auto consume = [&](const Step& r, const rg_u32x4& q4, int qk) {
       const bool ok = qk < r.q1;
-      const int o = 3 * qk;
+      // the record's pairs i = 0, 1, 2 belong to the lane's row iff lo <= i < lo + len (len = 0 for a lane without record)
+      const int lo = r.qs - 3 * qk;
+      const unsigned len = ok ? (unsigned)(r.qe - r.qs) : 0u;
       float w[3];
       int pos[3];
-      w[0] = __builtin_bit_cast(float, (q4.x & 0x3FFFFFFu) + w_base);
-      w[1] = __builtin_bit_cast(float, (q4.y & 0x3FFFFFFu) + w_base);
-      w[2] = __builtin_bit_cast(float, (q4.z & 0x3FFFFFFu) + w_base);
+      // w_base has its low 26 bits clear (the entry point checks), so code | w_base == code + w_base: one v_and_or_b32
+      w[0] = __builtin_bit_cast(float, (q4.x & 0x3FFFFFFu) | w_base);
+      w[1] = __builtin_bit_cast(float, (q4.y & 0x3FFFFFFu) | w_base);
+      w[2] = __builtin_bit_cast(float, (q4.z & 0x3FFFFFFu) | w_base);
       pos[0] = (int)(q4.w & 0xFFFFu);
       pos[1] = (int)(q4.w >> 16);
       pos[2] = (int)((q4.x >> 26) | ((q4.y >> 26) << 6) | ((q4.z >> 26) << 12));
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        const bool mine = ok && o + i >= r.qs && o + i < r.qe;
+        const bool mine = (unsigned)(i - lo) < len;
         const int p = pos[i] < nd_last ? pos[i] : nd_last;
         float v[STRIDE];
         if constexpr (kWindowed) {
           const int e = mine ? p : nd_all;          // not this row's pair: the all-EXCLUDED sentinel entry
           if constexpr (kNarrow) {
             v[0] = window[e * 3]; v[1] = window[e * 3 + 1]; v[2] = window[e * 3 + 2];
+          } else if constexpr (kPremask) {
+            const f32x2 term = (f32x2){w[i], w[i]} * reinterpret_cast<const f32x2*>(window)[e];
+            ap[0] += term.x;
+            aw[0] += term.y;
+            continue;
           } else if constexpr (STRIDE == 1) {
             v[0] = window[e];
           } else if constexpr (STRIDE == 2) {
@@ -839,7 +856,7 @@ int launch_rowwise(int window_cap, const void* indptr, const int64_t* dict_ptr, 
                    long n_vox, const float* packed, long n_gates, float fill, float* out, hipStream_t s,
                    const PackedStream& ps, int lanes_hint) {
   constexpr int STRIDE = stride_for(NF);
-  constexpr int WS = RowwiseConfig<NF>::narrow ? 3 : STRIDE;                     // floats per window entry
+  constexpr int WS = RowwiseConfig<NF>::narrow ? 3 : NF == 1 ? 2 : STRIDE;        // floats per window entry
   constexpr long kStatic = RowwiseConfig<NF>::regs ? 16 : (long)kH * 64 * NF * 8;   // the row-sum array, if any
   // one entry beyond window_cap: the sentinel; a smaller window only sends more chunks down the per-pair path
   const long room = (65536 - kStatic - 256) / (4 * WS) - 1;
@@ -900,6 +917,8 @@ extern "C" int rg_csr_compact_apply_packed_f32(const void* indptr, int32_t indpt
   RG_REQUIRE(window_cap >= 0 && window_cap <= RG_COMPACT_MAX_WINDOW, RG_EINVAL,
              "rg_csr_compact_apply_packed_f32: window_cap %d outside 0..%d", window_cap, RG_COMPACT_MAX_WINDOW);
   RG_REQUIRE(rg::aligned16(records), RG_EALIGN, "rg_csr_compact_apply_packed_f32: records must be 16-byte aligned");
+  RG_REQUIRE((w_base & 0x3FFFFFFu) == 0, RG_EINVAL,
+             "rg_csr_compact_apply_packed_f32: w_base=0x%08x must have its low 26 bits clear (exponent a multiple of 8)", w_base);
   if (n_vox == 0) return RG_OK;
   ChunkGrid cg;
   RG_REQUIRE(make_chunk_grid(n_vox, line_len, lines_per_plane, &cg), RG_EINVAL,

@@ -164,7 +164,10 @@ class RoiSearch:
         return DeviceCSR(indptr, gate_idx, weights, max_gate)
 
 
-_PACK_BASE_EXPONENT = {"barnes2": 121, "nearest": 127}   # smallest float32 exponent a weight can have (exp(-4)+1e-5 = 2^-6 * 1.17)
+# weightings whose weights fit the 26-bit code of the packed records, and the code's base: a float32 exponent that is a
+# multiple of 8 (the kernels OR it back in) and at most 7 below the largest exponent a weight can have.  barnes2:
+# exp(-4)+1e-5 = 2^-6 * 1.17 (exponent 121) .. 1+1e-5 (127); nearest: 1.0 (127)
+_PACK_BASE_EXPONENT = {"barnes2": 120, "nearest": 120}
 
 
 def _build_compact_only(search: "RoiSearch", weighting: str, pairs_per_slab: int = 1_200_000_000, packed: bool = False):

@@ -100,8 +100,10 @@ class CompactCSR:
             e = csr.weights[p0:p0 + step].view(torch.int32) >> 23
             a, b = int(e.min()), int(e.max())
             lo, hi = (a if lo is None else min(lo, a)), (b if hi is None else max(hi, b))
-        if lo <= 0 or hi - lo > 7 or hi >= 255:
-            logger.info(f"weights span exponents {lo}..{hi}: not codable in 26 bits, the compact copy keeps the plain arrays")
+        base = lo & ~7          # the code's base exponent: a multiple of 8, so that the kernels can OR it back in
+        if lo <= 0 or hi - base > 7 or hi >= 255:
+            logger.info(f"weights span exponents {lo}..{hi}: not codable in 26 bits above a base exponent that is a multiple "
+                        "of 8, the compact copy keeps the plain arrays")
             return False
         nz, ny, nx = self.grid_shape
         starts = torch.tensor(self.segment_starts(nx), device=dev, dtype=torch.int64)
@@ -116,7 +118,7 @@ class CompactCSR:
         n_rec = int(rec_ptr[-1])
         rec = torch.empty((max(n_rec, 1), 4), dtype=torch.int32, device=dev)[:n_rec]
         err = torch.zeros(1, dtype=torch.int32, device=dev)
-        w_base = lo << 23
+        w_base = base << 23
         with torch.cuda.device(dev):
             _native.check(lib.rg_csr_compact_pack(_native.ptr(csr.indptr), int(csr.is_i64), _native.ptr(self.local_idx),
                                                   _native.ptr(csr.weights), csr.n_vox, nx, ny, _native.ptr(rec_ptr), w_base,
@@ -160,9 +162,10 @@ class CompactCSR:
 
     @staticmethod
     def entry_bytes(n_fields: int) -> int:
-        """Bytes of one LDS window entry of the compact kernel: the packed slots of a gate (1, 2, 4 or 8 floats), a
-        3-field entry without its padding slot."""
-        return 4 * (1 if n_fields == 1 else 2 if n_fields == 2 else 3 if n_fields == 3 else 4 if n_fields == 4 else 8)
+        """Bytes of one LDS window entry of the compact kernels: the packed slots of a gate (2, 4 or 8 floats), a 3-field
+        entry without its padding slot; one field: the value and a 0/1 factor (row-wise kernel; the tile kernel keeps the
+        value alone)."""
+        return 4 * (2 if n_fields <= 2 else 3 if n_fields == 3 else 4 if n_fields == 4 else 8)
 
     def window_for(self, n_fields: int, lds_budget_bytes: int = 32768) -> int:
         """LDS window (entries) for a pass of ``n_fields`` fields: the geometry's 99.9 % window if its entries fit

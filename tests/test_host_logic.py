@@ -379,7 +379,7 @@ class TestCompactLayoutHostLogic:
         assert c.window_for(1) == 768 and c.window_for(2) == 768 and c.window_for(3) == 768 and c.window_for(8) == 768
         c.window_cap = 4096
         assert c.window_for(1) == 4096 and c.window_for(3) == 2688 and c.window_for(4) == 2048 and c.window_for(8) == 1024
-        assert [c.entry_bytes(n) for n in (1, 2, 3, 4, 5, 8)] == [4, 8, 12, 16, 32, 32]      # 32 KiB of LDS
+        assert [c.entry_bytes(n) for n in (1, 2, 3, 4, 5, 8)] == [8, 8, 12, 16, 32, 32]      # 32 KiB of LDS
         assert c.fallback_fraction(1000) == 0.0 and abs(c.fallback_fraction(850) - 0.7) < 1e-9
         assert abs(c.fallback_fraction(256) - 0.9) < 1e-9
 

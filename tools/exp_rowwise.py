@@ -69,8 +69,11 @@ def main():
             g.packed = ref.packed
             variants.append((f"row{code}", g, torch.empty_like(out_ref)))
         times = {v[0]: [] for v in variants}
+        rng = np.random.default_rng(7)
         for r in range(args.rounds + 1):
-            for name, g, out in variants:
+            order = list(range(len(variants))) if r == 0 else list(rng.permutation(len(variants)))   # position effects
+            for vi in order:                                                                            # are a few per cent
+                name, g, out = variants[vi]
                 ms = timed(lambda: g.apply(out))
                 if r:
                     times[name].append(ms)
