@@ -30,6 +30,8 @@ def main():
     dst = os.path.join(REPO, "profiles")
     os.makedirs(dst, exist_ok=True)
     stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+    if len(stats) > 1:      # gpurun MERGES into gpurun_out/: a second run of the same tag leaves the first run's files behind
+        sys.exit(f"{src} holds the output of {len(stats)} profiler runs: delete it locally and profile again")
     if stats:
         rows = list(csv.DictReader(open(stats[0])))
         with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
