@@ -3,8 +3,8 @@
 
     python tools/tune_compact.py [--config C2|METRIC|C4] [--fields 1,3] [--tiles 0,128,256] [--rounds 5]
 
-For every field count: rg_csr_apply_f32 (K1, the reference's CSR format) and rg_csr_compact_apply_f32 (K1c, compact copy)
-with each tile, median kernel time over the rounds, bytes per launch, TB/s, and whether K1c == K1 bit for bit for the
+For every field count: rg_csr_apply_f32 (K1, the reference's CSR format) and rg_csr_compact_apply_f32 (K1c TILE kernel over the
+compact arrays; the row-wise kernel over the packed records has its own script, exp_rowwise.py) with each tile, median kernel time over the rounds, bytes per launch, TB/s, and whether K1c == K1 bit for bit for the
 same tile.  Prints one JSON object."""
 import argparse
 import json
@@ -58,7 +58,7 @@ def main():
         for tile in [int(x) for x in args.tiles.split(",")]:
             try:
                 g_s = CsrGridder(geom, fl[0].numel(), nf, device=dev, tile=tile)
-                g_c = CsrGridder(geom, fl[0].numel(), nf, device=dev, compact=True, tile=tile)
+                g_c = CsrGridder(geom, fl[0].numel(), nf, device=dev, compact=True, tile=tile, packed=False)   # the tile kernel
             except Exception as exc:
                 rec["runs"].append({"fields": nf, "tile": tile, "error": repr(exc)})
                 continue
