@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Experiment: single-field compact kernel on the METRIC grid, tile x rotation sweep (interleaved rounds)."""
+"""Experiment: the single-field kernels over the compact copy on one grid (default METRIC), interleaved rounds: the
+row-wise kernel (tile 0), the tile kernel over the packed records with 384 / 576 / 768-pair tiles, and -- over the plain
+arrays -- the timing-only ablations of the tile kernel (tile codes 902-909: no row phase / no products / no window)."""
 import json, os, sys, tempfile
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,12 +21,11 @@ g.pack([f], [m])
 print('packed stream:', g.packed_stream, 'bytes/launch', g.compact_bytes())
 print('window', g.window, 'dict B/pair', 4 * g.compact.n_dict / g.csr.n_pairs, 'max_dict', g.compact.max_dict)
 out = torch.empty((1, g.n_vox), dtype=torch.float32, device=dev)
-variants = [(0, 0), (576, 0), (768, 0), (384, 5)]   # (0, 0) = what ships: the packed stream; 576/768 = packed, larger tiles   # 90x = timing-only ablations (no row phase / no products / no window)
+variants = [(0, 0), (384, 0), (576, 0), (768, 0), (902, 0), (903, 0), (909, 0)]
 times = {v: [] for v in variants}
 for rnd in range(6):
     for t, r in variants:
-        g.tile = 1000 * r + t
-        if r == 0: g.tile = t
+        g.tile = t
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); g.apply(out); e1.record(); e1.synchronize()
         if rnd:
