@@ -184,7 +184,7 @@ def csr_apply_f64(indptr, gate_indices, weights, field_values, field_mask, grid_
     out[ok] = (num[ok] / den[ok]).astype(np.float32)
     return out.reshape(grid_shape)
 
-ROWWISE_TARGET = {1: 4, 2: 6, 3: 6, 4: 8}   # records per lane and row the row-wise kernel aims for, by field count
+ROWWISE_TARGET = {1: 4, 2: 4, 3: 6, 4: 8}   # records per lane and row the row-wise kernel aims for, by field count
 
 
 def csr_apply_rowwise_order(indptr, gate_indices, weights, fields, masks, grid_shape, fill_value=np.nan,

@@ -583,7 +583,7 @@ namespace {
 
 template <int NF> struct RowwiseConfig;
 template <> struct RowwiseConfig<1> { static constexpr int kpre = 3, target = 4; static constexpr bool narrow = false, regs = false; };
-template <> struct RowwiseConfig<2> { static constexpr int kpre = 3, target = 6; static constexpr bool narrow = false, regs = false; };
+template <> struct RowwiseConfig<2> { static constexpr int kpre = 3, target = 4; static constexpr bool narrow = false, regs = false; };
 template <> struct RowwiseConfig<3> { static constexpr int kpre = 2, target = 6; static constexpr bool narrow = true, regs = true; };
 template <> struct RowwiseConfig<4> { static constexpr int kpre = 3, target = 8; static constexpr bool narrow = false, regs = true; };
 
