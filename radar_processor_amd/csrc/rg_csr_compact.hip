@@ -692,9 +692,13 @@ __global__ __launch_bounds__(64 * kH) void csr_compact_rowwise_kernel(
 
   // A STEP is one batch of KPRE record loads per lane: batch b of round rho.  A round whose rows need more than KPRE
   // trips simply takes several steps, so every load of the kernel is requested one step ahead whatever the row lengths.
+  // Per-step lane state is kept in the form the loop consumes it, so that a record costs one add and one compare to
+  // place: batch slot k of a step holds the lane's record number q + k * L.
   struct Step {
-    int qs, qe;        // the lane's row: pairs [qs, qe) of the segment
-    int q, q1;         // the lane's first record of this batch, end of the row's records
+    int lo0;           // (first pair of the lane's row) - 3 * q: pair i of slot k is the row's iff 0 <= i - lo < len,
+    unsigned len;      //   lo = lo0 - 3 * k * L; len = pairs of the row (0: no row)
+    int rem;           // records of the row from q on: slot k holds one iff k * L < rem
+    int off0;          // byte offset of record q in the segment's records
     int myrow, rho;
     int left;          // trips of the round still to do, this batch included (wave-uniform)
     bool live;
@@ -704,19 +708,27 @@ __global__ __launch_bounds__(64 * kH) void csr_compact_rowwise_kernel(
     r.rho = rho;
     r.myrow = rho * rpr + rgrp;
     r.live = r.myrow < nrows;
-    r.qs = __shfl(rs_o, r.myrow & 63, 64);
-    const int qe = __shfl(re_o, r.myrow & 63, 64);
-    r.qe = r.live ? qe : r.qs;
-    const unsigned q0 = (unsigned)r.qs / 3u;
-    r.q1 = r.qe > r.qs ? (int)(((unsigned)r.qe + 2u) / 3u) : (int)q0;
-    r.q = (int)q0 + sub;
+    // both shuffles unconditional: a lane that is dead in this round still has to SUPPLY its row bounds (a shuffle
+    // under a divergent condition reads zeros from the lanes that skipped it)
+    const int qs = __shfl(rs_o, r.myrow & 63, 64);
+    const int qe_row = __shfl(re_o, r.myrow & 63, 64);
+    const int qe = r.live ? qe_row : qs;
+    const int q0 = (int)((unsigned)qs / 3u);
+    const int q1 = qe > qs ? (int)(((unsigned)qe + 2u) / 3u) : q0;
+    const int q = q0 + sub;
+    r.lo0 = qs - 3 * q;
+    r.len = (unsigned)(qe - qs);
+    r.rem = q1 - q;
+    r.off0 = q * 16;
     r.left = rho < rounds ? __builtin_amdgcn_readfirstlane(__shfl(trips_row, (rho * rpr) & 63, 64)) : 0;
     return r;
   };
   auto advance = [&](const Step& r) -> Step {      // the step after r (wave-uniform choice)
     if (r.left > KPRE) {
       Step n = r;
-      n.q += KPRE << lgl;
+      n.lo0 -= 3 * (KPRE << lgl);
+      n.rem -= KPRE << lgl;
+      n.off0 += 16 * (KPRE << lgl);
       n.left -= KPRE;
       return n;
     }
@@ -724,31 +736,34 @@ __global__ __launch_bounds__(64 * kH) void csr_compact_rowwise_kernel(
   };
   auto issue = [&](const Step& r, rg_u32x4 (&regs)[KPRE]) {
 #pragma unroll
-    for (int k = 0; k < KPRE; ++k) {
-      const int qk = r.q + (k << lgl);
-      regs[k] = rg_buffer_load_v4u32(rr, qk < r.q1 ? qk * 16 : kOutOfRange, 0, 0);
-    }
+    for (int k = 0; k < KPRE; ++k)
+      regs[k] = rg_buffer_load_v4u32(rr, (k << lgl) < r.rem ? r.off0 + 16 * (k << lgl) : kOutOfRange, 0, 0);
   };
+  // 26-bit weight mask in a VGPR the compiler cannot fold: (x & mask) | w_base is then ONE v_and_or_b32 (this ISA's VOP3
+  // takes no literal, and a literal mask splits it into v_and + v_or)
+  unsigned wmask = 0x3FFFFFFu;
+  asm volatile("" : "+v"(wmask));
 
   auto run = [&](auto wtag) {
     constexpr bool kWindowed = decltype(wtag)::value;
     float ap[NF], aw[NF];                           // the running sums of the lane's row, across the round's steps
 #pragma unroll
     for (int f = 0; f < NF; ++f) ap[f] = aw[f] = 0.0f;
-    auto consume = [&](const Step& r, const rg_u32x4& q4, int qk) {
-      const bool ok = qk < r.q1;
+    auto consume = [&](const Step& r, const rg_u32x4& q4, int k) {     // k: slot of the step's batch (compile-time)
       // the record's pairs i = 0, 1, 2 belong to the lane's row iff lo <= i < lo + len (len = 0 for a lane without record)
-      const int lo = r.qs - 3 * qk;
-      const unsigned len = ok ? (unsigned)(r.qe - r.qs) : 0u;
+      const int lo = r.lo0 - 3 * (k << lgl);
+      const unsigned len = (k << lgl) < r.rem ? r.len : 0u;
       float w[3];
       int pos[3];
-      // w_base has its low 26 bits clear (the entry point checks), so code | w_base == code + w_base: one v_and_or_b32
-      w[0] = __builtin_bit_cast(float, (q4.x & 0x3FFFFFFu) | w_base);
-      w[1] = __builtin_bit_cast(float, (q4.y & 0x3FFFFFFu) | w_base);
-      w[2] = __builtin_bit_cast(float, (q4.z & 0x3FFFFFFu) | w_base);
+      // w_base has its low 26 bits clear (the entry point checks), so code | w_base == code + w_base
+      w[0] = __builtin_bit_cast(float, (q4.x & wmask) | w_base);
+      w[1] = __builtin_bit_cast(float, (q4.y & wmask) | w_base);
+      w[2] = __builtin_bit_cast(float, (q4.z & wmask) | w_base);
       pos[0] = (int)(q4.w & 0xFFFFu);
       pos[1] = (int)(q4.w >> 16);
-      pos[2] = (int)((q4.x >> 26) | ((q4.y >> 26) << 6) | ((q4.z >> 26) << 12));
+      unsigned p2b = q4.y >> 26, p2c = q4.z >> 26;
+      asm volatile("" : "+v"(p2b), "+v"(p2c));     // keep the shifts apart: each OR then folds into a v_lshl_or_b32
+      pos[2] = (int)((p2c << 12) | ((p2b << 6) | (q4.x >> 26)));
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         const bool mine = (unsigned)(i - lo) < len;
@@ -792,7 +807,7 @@ __global__ __launch_bounds__(64 * kH) void csr_compact_rowwise_kernel(
     auto process = [&](const Step& r, const rg_u32x4 (&regs)[KPRE], bool last) {
 #pragma unroll
       for (int k = 0; k < KPRE; ++k) {
-        if (k < r.left) consume(r, regs[k], r.q + (k << lgl));   // wave-uniform
+        if (k < r.left) consume(r, regs[k], k);   // wave-uniform
       }
       if (!last) return;
       float sv[2 * NF];
