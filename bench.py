@@ -66,6 +66,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-compact", action="store_true",
                     help="csr mode: run the standard 8-byte-per-pair kernel instead of the compact device copy of the "
                          "CSR (the same values to float32 rounding)")
+    ap.add_argument("--layout", default="auto", choices=("auto", "csr", "compact", "packed"),
+                    help="csr mode: geometry layout handed to compute_grid_geometry (auto = the reference's arrays + the "
+                         "compact copy when both fit, the packed layout alone otherwise)")
     ap.add_argument("--tile-kernel", action="store_true",
                     help="csr mode, A/B: run the tile kernel over the packed records (bit-identical to the standard kernel) "
                          "instead of the row-wise kernel")
@@ -389,7 +392,7 @@ def run_rank(args):
             fields_per_pass = min(4 if c5 else 8, n_ff)     # C5: VolumeBatch fuses up to 4 field-volumes into one CSR pass
             want_compact = not args.no_compact
             geom = rg.compute_grid_geometry(vol.gate_x, vol.gate_y, vol.gate_z, shape, limits, tmp,
-                                            layout="auto" if want_compact else "csr")
+                                            layout=args.layout if want_compact else "csr")
         if want_compact and geom.device_csr(dev).gate_indices is not None:
             free_b, _ = torch.cuda.mem_get_info(dev)              # room for the copy (2.3 bytes per pair + scratch)?
             want_compact = free_b > 3.2 * geom.n_pairs() + (8 << 30)
