@@ -4,10 +4,11 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config METRIC|C2|C4|C5] [--fields F] [--mode csr|fused]
 
 One *step* = one pass of the per-volume hot path over one batch of synthetic input per GPU, inputs resident in HBM:
-mask fold + field interleave (rg_pack_fields_f32) -> gridding (rg_csr_compact_apply_f32 / rg_csr_apply_f32, the
-dominant kernel) -> COLMAX+argmax (rg_column_reduce_f32) -> CAPPI@4000 m (rg_cappi_lerp_f32).  The geometry (CSR) is
-built once on the GPU before the timed region -- that is how the reference uses it too (once per scan strategy,
-SURVEY.md §3.1).
+mask fold + field interleave (rg_pack_fields_f32) -> gridding (the dominant kernel: rg_csr_compact_apply_packed_f32 =
+the row-wise kernel over the packed records of the compact CSR copy; rg_csr_compact_apply_f32 / rg_csr_apply_f32 with
+--tile-kernel / --no-compact or where the weights are not codable) -> COLMAX+argmax (rg_column_reduce_f32) ->
+CAPPI@4000 m (rg_cappi_lerp_f32).  The geometry (CSR) is built once on the GPU before the timed region -- that is how the
+reference uses it too (once per scan strategy).
 
 Default workload (N=1): the configuration BASELINE.json's metric is quoted on -- the 12-elevation 360x1000-gate
 volume onto the 40x2000x2000 grid, one field (DBZH), one volume per GPU per step.
@@ -69,6 +70,9 @@ def parse_args(argv=None):
     ap.add_argument("--layout", default="auto", choices=("auto", "csr", "compact", "packed"),
                     help="csr mode: geometry layout handed to compute_grid_geometry (auto = the reference's arrays + the "
                          "compact copy when both fit, the packed layout alone otherwise)")
+    ap.add_argument("--rec-order", default="dispatch", choices=("dispatch", "segment"),
+                    help="csr mode: order in which the packed records are stored -- dispatch (the order the workgroups read "
+                         "them: one moving front) or segment (line-major segments, round 2's layout; A/B only)")
     ap.add_argument("--tile-kernel", action="store_true",
                     help="csr mode, A/B: run the tile kernel over the packed records (bit-identical to the standard kernel) "
                          "instead of the row-wise kernel")
@@ -76,6 +80,12 @@ def parse_args(argv=None):
                     help="process-group backend for N>1 (nccl = RCCL; gloo only for rehearsing ranks on one GPU)")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal: every rank uses cuda:0 (needs --dist-backend gloo; RCCL refuses a shared GPU)")
+    ap.add_argument("--pg-timeout", type=float, default=120.0,
+                    help="N>1: seconds a rank waits in the rendezvous / a collective before it gives up")
+    ap.add_argument("--fail-rank", type=int, default=-1,
+                    help="test hook: this rank exits with code 3 before the rendezvous (exercises the launcher's failure path)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="test hook: the ranks only meet in a gloo process group (no GPU work) and rank 0 prints a JSON line")
     ap.add_argument("--cpu-sample-pairs", type=float, default=1.5e9, help="upper bound on CSR pairs in the CPU sample")
     ap.add_argument("--cpu-workers", type=int, default=0,
                     help="processes of the all-core CPU leg (0 = min(usable cores, 16): the CPU share of a 1-GPU box)")
@@ -91,11 +101,17 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-def spawn_ranks(args) -> int:
+def spawn_ranks(args, argv=None, poll_s: float = 0.2, grace_s: float = 10.0) -> int:
     """Start ``args.gpus`` fresh child processes, one per GPU, and pass rank 0's stdout through.  Nothing in THIS
     process touches the GPU (no HIP call, no exec after one): the library is compiled if missing (hipcc, CPU only),
     the device count is read with ``torch.cuda.device_count()`` (which does not initialise the runtime on this
-    image), then the children are started with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set."""
+    image), then the children are started with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set.
+
+    Failure path: all children are polled; as soon as ONE exits non-zero its siblings -- which would otherwise sit in
+    the rendezvous or in a barrier until the process-group timeout -- are terminated (SIGTERM, SIGKILL after
+    ``grace_s``) and the launcher returns non-zero within seconds, without a JSON line.  Only fresh children are ever
+    started; nothing that has touched the GPU is re-executed."""
+    import threading
     from radar_processor_amd.build import ensure_built
     ensure_built(verbose=True)
     n = args.gpus
@@ -112,15 +128,38 @@ def spawn_ranks(args) -> int:
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         env.setdefault("OMP_NUM_THREADS", "2")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0.decode())
-    sys.stdout.flush()
-    if any(codes):
-        log(f"rank exit codes: {codes}")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *(sys.argv[1:] if argv is None else argv)],
+                                      env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    chunks = []                       # rank 0's stdout is drained by a thread, so that polling never blocks on the pipe
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = bad[0]
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(poll_s)
+    if failed is not None:
+        log(f"rank {failed[0]} exited with code {failed[1]}: stopping the other ranks")
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        deadline = time.time() + grace_s
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+        log(f"rank exit codes: {[p.returncode for p in procs]}")
         return 1
+    reader.join(timeout=30)
+    sys.stdout.write(b"".join(chunks).decode())
+    sys.stdout.flush()
     return 0
 
 
@@ -310,6 +349,21 @@ def run_rank(args):
             f"spawns its own ranks) or under `python -m torch.distributed.run --nproc-per-node {args.gpus}`")
         return 2
 
+    if args.fail_rank == rank:
+        log(f"rank {rank}: --fail-rank, exiting before the rendezvous")
+        return 3
+
+    if args.rendezvous_only:                 # launcher rehearsal on a box without GPUs: rendezvous, barrier, done
+        from datetime import timedelta
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", timeout=timedelta(seconds=args.pg_timeout))
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps({"rendezvous": "ok", "n_gpus": dist.get_world_size()}), flush=True)
+        dist.destroy_process_group()
+        return 0
+
     # ---- everything that creates processes happens BEFORE the GPU is touched ---------------------------------
     from radar_processor_amd.build import ensure_built
     ensure_built(verbose=rank == 0)              # bare checkout: compile the git-ignored library (file-locked)
@@ -336,10 +390,12 @@ def run_rank(args):
     dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        from datetime import timedelta
+        pg_timeout = timedelta(seconds=args.pg_timeout)       # a rank that never arrives fails the others, not hangs them
         if args.dist_backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)      # RCCL over xGMI
+            dist.init_process_group(backend="nccl", device_id=dev, timeout=pg_timeout)      # RCCL over xGMI
         else:
-            dist.init_process_group(backend="gloo")
+            dist.init_process_group(backend="gloo", timeout=pg_timeout)
         assert dist.get_world_size() == world
     rg.load_library()
 
@@ -386,6 +442,9 @@ def run_rank(args):
     gridder = search = None
     if args.mode == "csr":
         import tempfile
+        from radar_processor_amd import _native, grid_geometry
+        grid_geometry.DEFAULT_REC_ORDER = (_native.RG_REC_ORDER_DISPATCH if args.rec_order == "dispatch"
+                                           else _native.RG_REC_ORDER_SEGMENT)
         with tempfile.TemporaryDirectory() as tmp:
             # passes run through the compact copy of the CSR; 'auto' keeps the reference's index array next to it when
             # both fit and builds the copy alone otherwise (config 4: 33 G pairs)
@@ -476,7 +535,12 @@ def run_rank(args):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else float("nan")
+    launch_ms = np.array([a.elapsed_time(b) for a, b in events], dtype=np.float64)
+    kernel_ms = float(launch_ms.mean()) if events else float("nan")
+    # one stderr line per rank: an N-GPU line (max over ranks) can be attributed to the rank that set it
+    if events:
+        log(f"rank {rank}: {elapsed / args.steps * 1e3:.3f} ms/step, gridding launches min/median/mean/max "
+            f"{launch_ms.min():.3f}/{np.median(launch_ms):.3f}/{kernel_ms:.3f}/{launch_ms.max():.3f} ms over {len(events)}")
 
     # ---- the grid that was just timed is checked, outside the timed region (rank 0) ------------------------------
     # the compact kernel against the reference-format kernel on the same inputs, every voxel: the row-wise kernel to
@@ -549,7 +613,9 @@ def run_rank(args):
                        "pairs": n_pairs, "fields_per_pass": fields_per_pass, "volumes_total": total_vol,
                        "ranks_seen_by_process_group": dist.get_world_size() if world > 1 else 1,
                        "checked": checked,
-                       "step": "pack_fields + " + (("csr_compact_apply" if compact_on else "csr_apply") if args.mode == "csr"
+                       "record_order": (args.rec_order if args.mode == "csr" and gridder.compact is not None
+                                 and gridder.packed_stream else None),
+                "step": "pack_fields + " + (("csr_compact_apply" if compact_on else "csr_apply") if args.mode == "csr"
                                                    else "roi_grid")
                                + " + colmax/argmax + cappi4000 per field-volume"},
             "roofline": {
@@ -563,6 +629,10 @@ def run_rank(args):
                 "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": int(algo_bytes),
                 "kernel_ms": round(kernel_ms, 4),
+                "kernel_ms_min": round(float(launch_ms.min()), 4) if events else None,
+                "kernel_ms_median": round(float(np.median(launch_ms)), 4) if events else None,
+                "kernel_ms_max": round(float(launch_ms.max()), 4) if events else None,
+                "launches_timed": len(events),
                 "launches_per_step": launches_per_step,
                 # the same launch priced in the reference's CSR format (8 bytes per pair); larger than
                 # `achieved` when the compact device copy is in use, because that kernel moves fewer bytes per pair
@@ -583,8 +653,9 @@ def run_rank(args):
             if ceiling:
                 result["roofline"]["ceiling_measured"] = round(ceiling, 1)
                 result["roofline"]["frac_of_ceiling"] = round(achieved / ceiling, 4)
-                result["roofline"]["ceiling_how"] = ("rg_stream_read_probe: grid-stride dwordx4 read of the largest resident "
-                                                     "buffer, no stores, best of 5, same process, untimed")
+                result["roofline"]["ceiling_how"] = ("rg_stream_read_probe: one dwordx4 per lane over the largest resident "
+                                                     "buffer, workgroups in address order, no stores, best of 5, same "
+                                                     "process, untimed (a pure read; the gridding kernel also writes the grid)")
         except Exception as exc:
             log(f"ceiling probe failed: {exc!r}")
         if c5:
@@ -671,6 +742,8 @@ def run_rank(args):
             except Exception as exc:   # never lose the GPU line to a host-side problem
                 log(f"cpu baseline failed: {exc!r}")
                 result["cpu_baseline"] = None
+        elif world > 1:
+            result["cpu_baseline"] = {"skipped": "N>1: the host-core baseline is timed on rank 0 of the N=1 line only"}
         print(json.dumps(result), flush=True)
     if pool is not None:
         pool.close()

@@ -322,6 +322,11 @@ int rg_grid_filter(const void* src, int32_t data_is_f64, int64_t n, int32_t flag
 #define RG_COMPACT_LINES 4
 #endif
 #define RG_COMPACT_MAX_WINDOW 8192
+/* Block -> chunk map of the apply kernels: block b = (line group grp, column col) takes chunk column
+ * (col + (grp * RG_COMPACT_ROTATION) mod nsx) mod nsx of its line group (grp counted through all planes, 32-bit unsigned
+ * arithmetic), so that every XCD sees every column of the grid.  Part of the record layout when the records are stored
+ * in dispatch order (below). */
+#define RG_COMPACT_ROTATION 5
 int rg_csr_compact_apply_f32(const void* indptr, int32_t indptr_is_i64, const uint16_t* local_idx, const float* weights,
                              const int64_t* dict_ptr, const int32_t* dict, int64_t n_vox, int64_t n_pairs,
                              int64_t line_len, int64_t lines_per_plane, const float* packed, int32_t n_fields,
@@ -334,10 +339,17 @@ int rg_csr_compact_apply_f32(const void* indptr, int32_t indptr_is_i64, const ui
  *   weight code = float32 bits of the weight - w_base; w_base has its low 26 bits clear (an exponent that is a multiple of
  *   8, shifted left by 23), so adding it back is an OR; the caller guarantees that every code fits 26 bits (all weights
  *   positive, exponents w_base >> 23 .. (w_base >> 23) + 7), which makes the coding lossless.
- * Segments (the <= 64 rows one wavefront owns) are numbered line-major, seg = line * ceil(line_len / 64) + sx; segment
- * seg owns records rec_ptr[seg] .. rec_ptr[seg+1], ceil(pairs / 3) of them and fewer than 2^27 (rec_ptr has segments + 1
- * entries, built by the caller).  rg_csr_compact_pack fills `records` from local_idx + weights (error_flag: 1 = rec_ptr
- * inconsistent with indptr, 2 = a weight outside the code, 4 = a segment with 2^27 records or more).
+ * A segment (the <= 64 rows one wavefront owns) holds ceil(pairs / 3) records, fewer than 2^27; where they lie is
+ * rec_order's business -- rec_ptr[s] .. rec_ptr[s+1] are the records of the segment in SLOT s:
+ *   RG_REC_ORDER_SEGMENT   s = seg = line * ceil(line_len / 64) + sx (line-major; rec_ptr has segments + 1 entries);
+ *   RG_REC_ORDER_DISPATCH  s = b * RG_COMPACT_LINES + w for the segment wavefront w of block b reads (block -> chunk map:
+ *                          RG_COMPACT_ROTATION above; rec_ptr has chunks * RG_COMPACT_LINES + 1 entries, slots of lines
+ *                          past the end of a plane are empty).  The four segments of a workgroup are then neighbours in
+ *                          the stream and consecutive workgroups read consecutive stretches of it: whatever the physical
+ *                          placement of the array, the launch reads it as ONE moving front.
+ * rec_ptr is built by the caller.  rg_csr_compact_pack fills `records` from local_idx + weights (error_flag: 1 = rec_ptr
+ * inconsistent with indptr, 2 = a weight outside the code, 4 = a segment with 2^27 records or more); for a slab of whole
+ * planes of a larger grid pass the slab's indptr / n_rows, rec_ptr + the slab's first slot and plane0 = its first plane.
  * rg_csr_compact_apply_packed_f32 grids 1-4 fused fields through the records (interpolate.py:69-104, the same masked
  * weighted mean as rg_csr_apply_f32: float32 products and sums, float64 only in the final division):
  *   tile = 0    the ROW-WISE kernel: the lanes of a row read the row's records straight from memory and sum them in
@@ -351,11 +363,14 @@ int rg_csr_compact_apply_f32(const void* indptr, int32_t indptr_is_i64, const ui
  *   tile = 2000 + h   row-wise with a diagnostic lane split: h = 1, 2, 4 .. 64 lanes per row, or h = 70 + t to aim for t
  *               records per lane and row (another split = another order of the adds).
  * window_cap as for rg_csr_compact_apply_f32; the row-wise kernel keeps one entry more (an all-EXCLUDED sentinel). */
+#define RG_REC_ORDER_SEGMENT 0
+#define RG_REC_ORDER_DISPATCH 1
 int rg_csr_compact_pack(const void* indptr, int32_t indptr_is_i64, const uint16_t* local_idx, const float* weights,
                         int64_t n_rows, int64_t line_len, int64_t lines_per_plane, const int64_t* rec_ptr,
-                        uint32_t w_base, void* records, int32_t* error_flag, rg_stream_t stream);
+                        int32_t rec_order, int64_t plane0, uint32_t w_base, void* records, int32_t* error_flag,
+                        rg_stream_t stream);
 int rg_csr_compact_apply_packed_f32(const void* indptr, int32_t indptr_is_i64, const void* records,
-                                    const int64_t* rec_ptr, uint32_t w_base, const int64_t* dict_ptr,
+                                    const int64_t* rec_ptr, int32_t rec_order, uint32_t w_base, const int64_t* dict_ptr,
                                     const int32_t* dict, int64_t n_vox, int64_t n_pairs, int64_t line_len,
                                     int64_t lines_per_plane, const float* packed, int32_t n_fields, int32_t stride,
                                     int64_t n_gates, float fill_value, float* out, int32_t window_cap, int32_t tile,

@@ -188,7 +188,7 @@ ROWWISE_TARGET = {1: 4, 2: 4, 3: 6, 4: 8}   # records per lane and row the row-w
 
 
 def csr_apply_rowwise_order(indptr, gate_indices, weights, fields, masks, grid_shape, fill_value=np.nan,
-                            lanes_hint: int = 0) -> np.ndarray:
+                            lanes_hint: int = 0, fold: str = "f64") -> np.ndarray:
     """The masked weighted mean of :func:`csr_apply` (interpolate.py:69-104) with the float32 additions performed in
     exactly the order the row-wise kernel of ``rg_csr_compact_apply_packed_f32`` documents
     (radar_processor_amd/csrc/rg_csr_compact.hip), so that the kernel can be checked BIT FOR BIT on small cases:
@@ -254,10 +254,12 @@ def csr_apply_rowwise_order(indptr, gate_indices, weights, fields, masks, grid_s
                     with np.errstate(invalid="ignore", over="ignore"):
                         sp = np.add.accumulate(mp, axis=1, dtype=np.float32)[:, -1]    # strictly sequential per lane
                         sw = np.add.accumulate(mw, axis=1, dtype=np.float32)[:, -1]
+                        fdt = np.float64 if fold == "f64" else np.float32
+                        sp, sw = sp.astype(fdt), sw.astype(fdt)
                         m = 1
                         while m < lanes:
                             partner = np.arange(lanes) ^ m
-                            sp, sw = (sp + sp[partner]).astype(np.float32), (sw + sw[partner]).astype(np.float32)
+                            sp, sw = (sp + sp[partner]).astype(fdt), (sw + sw[partner]).astype(fdt)
                             m <<= 1
                         if sw[0] > 0:
                             out[f, r] = np.float32(np.float64(sp[0]) / np.float64(sw[0]))

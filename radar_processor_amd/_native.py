@@ -27,6 +27,8 @@ RG_MINMAX_WORKSPACE_BYTES = 32768
 RG_MAX_LUT = 4093
 RG_COMPACT_LINES = 4          # grid lines (= wavefronts) per chunk of the compact CSR copy (header: RG_COMPACT_LINES)
 RG_COMPACT_MAX_WINDOW = 8192
+RG_COMPACT_ROTATION = 5       # block -> chunk column rotation per line group (header: RG_COMPACT_ROTATION)
+RG_REC_ORDER_SEGMENT, RG_REC_ORDER_DISPATCH = 0, 1
 
 
 class NativeUnavailable(RuntimeError):
@@ -76,8 +78,8 @@ SIGNATURES = {
                                            c_int64, c_int64, c_void_p, c_int32, c_int32, c_int64, c_float, c_void_p,
                                            c_int32, c_int32, c_void_p]),
     "rg_csr_compact_pack": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p,
-                                      ctypes.c_uint32, c_void_p, c_void_p, c_void_p]),
-    "rg_csr_compact_apply_packed_f32": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, ctypes.c_uint32, c_void_p,
+                                      c_int32, c_int64, ctypes.c_uint32, c_void_p, c_void_p, c_void_p]),
+    "rg_csr_compact_apply_packed_f32": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, ctypes.c_uint32, c_void_p,
                                                   c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int32,
                                                   c_int32, c_int64, c_float, c_void_p, c_int32, c_int32, c_void_p]),
     "rg_csr_compact_chunks": (c_int64, [c_int64, c_int64, c_int64]),

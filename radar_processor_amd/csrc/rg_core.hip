@@ -186,24 +186,19 @@ extern "C" int rg_pack_fields_f32(int32_t n_fields, const float* const* fields_h
 
 // ---------------------------------------------------------------------------------------------------------------
 // Measurement aid (bench.py's roofline.ceiling_measured): what read bandwidth does this GPU deliver to a kernel that
-// only streams a large array?  Grid-stride dwordx4 reads, four independent loads in flight per lane, no stores.
+// only streams a large array?  One dwordx4 per lane, workgroup b reads bytes [4096 b, 4096 b + 4096): the dispatcher
+// hands the array out front to back in 4 KiB pieces.  No loop, no stores.  (Round 3: this shape reads 6.7-6.8 TB/s where
+// the grid-stride loop of rounds 1-2 -- 8192 workgroups, four loads in flight per lane -- read 6.1-6.4 on the same
+// boxes; tools/exp_placement3.py.  A ceiling should be the best known pattern.)
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
 __global__ __launch_bounds__(256) void stream_read_kernel(const float4* __restrict__ a, long n16,
                                                           float* __restrict__ sink) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
   float acc = 0.0f;
-  const long stride = (long)gridDim.x * blockDim.x;
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  for (; i + 3 * stride < n16; i += 4 * stride) {
-    float4 v[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = a[i + u * stride];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) acc += v[u].x + v[u].y + v[u].z + v[u].w;
-  }
-  for (; i < n16; i += stride) {
+  if (i < n16) {
     const float4 v = a[i];
-    acc += v.x + v.y + v.z + v.w;
+    acc = v.x + v.y + v.z + v.w;
   }
   if (acc == 123.456f) sink[0] = acc;   // practically never true: keeps the loads alive without a store stream
 }
@@ -212,7 +207,9 @@ __global__ __launch_bounds__(256) void stream_read_kernel(const float4* __restri
 extern "C" int rg_stream_read_probe(const void* buffer, int64_t bytes, float* sink, rg_stream_t stream) {
   RG_REQUIRE(buffer && sink && bytes >= 16, RG_EINVAL, "rg_stream_read_probe: null buffer/sink or fewer than 16 bytes");
   RG_REQUIRE(rg::aligned16(buffer), RG_EALIGN, "rg_stream_read_probe: buffer must be 16-byte aligned");
-  hipLaunchKernelGGL(stream_read_kernel, dim3(8192), dim3(256), 0, (hipStream_t)stream,
-                     static_cast<const float4*>(buffer), (long)(bytes / 16), sink);
+  const long n16 = bytes / 16, blocks = (n16 + 255) / 256;
+  RG_REQUIRE(blocks <= 0x7FFFFFFFL, RG_EUNSUPPORTED, "rg_stream_read_probe: more than 2^31 workgroups (8 TiB)");
+  hipLaunchKernelGGL(stream_read_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     static_cast<const float4*>(buffer), n16, sink);
   return rg::check_launch("rg_stream_read_probe");
 }

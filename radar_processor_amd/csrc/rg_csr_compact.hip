@@ -67,7 +67,21 @@ struct ChunkGrid {
   unsigned rot_step;        // columns the block -> chunk map rotates per line group (speed only)
   unsigned seg_base;        // a line's nsx segments are balanced: the first seg_extra hold seg_base + 1 rows, the
   unsigned seg_extra;       // others seg_base (<= 64 either way) -- rg_csr_apply_f32 cuts its lines the same way
+  unsigned grp0;            // line groups in front of this grid when it is a slab of whole planes of a larger one
+                            // (rg_csr_compact_pack's plane0 * nyg; 0 for the apply kernels): the rotation counts them
 };
+
+// Workgroups are dealt to the 8 XCDs round-robin by blockIdx.  With nsx segments per line a multiple of 8, chunk column
+// sx would always land on XCD sx % 8 and each XCD would own one x-slab of the grid for the whole launch; rotating the
+// columns by rot_step per line group makes every XCD see every column.  The chunk a workgroup takes is a bijection of
+// blockIdx; with RG_REC_ORDER_DISPATCH the records are STORED in this order (see rg_csr_compact_pack), so the map is part
+// of the layout: grid_geometry.CompactCSR.slot_of_segments restates it.
+__device__ __forceinline__ unsigned block_chunk(const ChunkGrid& g, unsigned bid) {
+  const unsigned grp = bid / g.nsx;
+  const unsigned col = bid - grp * g.nsx;
+  const unsigned rot = col + ((grp + g.grp0) * g.rot_step) % g.nsx;
+  return grp * g.nsx + (rot >= g.nsx ? rot - g.nsx : rot);
+}
 
 __host__ __device__ inline long chunk_count(const ChunkGrid& g) { return g.n_planes * (long)g.nyg * (long)g.nsx; }
 
@@ -106,7 +120,8 @@ __global__ __launch_bounds__(64 * kH) void csr_compact_kernel(
     const IndT* __restrict__ indptr, const uint16_t* __restrict__ lidx, const float* __restrict__ wts,
     const int64_t* __restrict__ dict_ptr, const int32_t* __restrict__ dict, ChunkGrid cg,
     const float* __restrict__ packed, unsigned last_gate, float fill, int window_cap, long n_vox,
-    float* __restrict__ out, const rg_u32x4* __restrict__ rec, const int64_t* __restrict__ rec_ptr, unsigned w_base) {
+    float* __restrict__ out, const rg_u32x4* __restrict__ rec, const int64_t* __restrict__ rec_ptr, unsigned w_base,
+    int rec_order) {
   static_assert(TILE % 64 == 0, "a wave handles 64 pairs per step");
   static_assert(!PACKED || TILE % 192 == 0, "a packed tile is whole wave-loads of 64 three-pair records");
   constexpr int IT = TILE / 64;
@@ -121,14 +136,7 @@ __global__ __launch_bounds__(64 * kH) void csr_compact_kernel(
   float* tile = tile_all[wv];
   f32x2* rowacc = rowacc_all[wv];
 
-  // Workgroups are dealt to the 8 XCDs round-robin by blockIdx.  With nsx segments per line a multiple of 8, chunk
-  // column sx would always land on XCD sx % 8; rotating the columns by one per line group makes every XCD see every
-  // column (speed only: the chunk a workgroup takes is still a bijection of blockIdx).
-  const unsigned bid = blockIdx.x;
-  const unsigned grp = bid / cg.nsx;
-  const unsigned col = bid - grp * cg.nsx;
-  const unsigned rot = (col + (grp * cg.rot_step) % cg.nsx);
-  const unsigned chunk = grp * cg.nsx + (rot >= cg.nsx ? rot - cg.nsx : rot);
+  const unsigned chunk = block_chunk(cg, blockIdx.x);
   const long d0 = dict_ptr[chunk];
   // A chunk's dictionary holds at most 65536 gates (positions are 16 bits).  The one exception is a SPLIT chunk -- more
   // distinct gates than that, as around the radar itself on a dense scan --, which stores one dictionary per wavefront
@@ -170,8 +178,9 @@ __global__ __launch_bounds__(64 * kH) void csr_compact_kernel(
   long rec_b = 0, rec_n = 0;                 // this segment's records (PACKED)
   if constexpr (PACKED) {
     if (nrows) {
-      rec_b = rec_ptr[sg.seg];
-      rec_n = rec_ptr[sg.seg + 1] - rec_b;
+      const long slot = rec_order == RG_REC_ORDER_DISPATCH ? (long)blockIdx.x * kH + wv : sg.seg;
+      rec_b = rec_ptr[slot];
+      rec_n = rec_ptr[slot + 1] - rec_b;
     }
   }
   auto stream = [&](Stage& sgs, int t) {   // t wave-uniform: the resources live in SGPRs
@@ -329,6 +338,7 @@ struct PackedStream {   // the packed form of positions + weights (rg_csr_compac
   const rg_u32x4* rec = nullptr;
   const int64_t* rec_ptr = nullptr;
   unsigned w_base = 0;
+  int order = RG_REC_ORDER_SEGMENT;
 };
 
 template <typename IndT, int NF, int TILE, int ABLATE = 0, int AUX = 0, bool PACKED = false>
@@ -344,7 +354,7 @@ int launch_nf(int window_cap, const void* indptr, const uint16_t* lidx, const fl
   hipLaunchKernelGGL((csr_compact_kernel<IndT, NF, STRIDE, TILE, ABLATE, AUX, PACKED>), dim3((unsigned)chunk_count(cg)),
                      dim3(64 * kH), ((size_t)window_cap * WS * sizeof(float) + 15) / 16 * 16, s,
                      static_cast<const IndT*>(indptr), lidx, wts, dict_ptr, dict, cg, packed, (unsigned)(n_gates - 1), fill,
-                     window_cap, n_vox, out, ps.rec, ps.rec_ptr, ps.w_base);
+                     window_cap, n_vox, out, ps.rec, ps.rec_ptr, ps.w_base, ps.order);
   return rg::check_launch("rg_csr_compact_apply_f32");
 }
 
@@ -419,7 +429,8 @@ bool make_chunk_grid(int64_t n_rows, int64_t line_len, int64_t lines_per_plane, 
   cg->seg_extra = (unsigned)(line_len % nsx);
   // measured on the bench grid (32 columns), ms per launch: 0 -> 14.2 (every XCD keeps its columns), 8 -> 10.5,
   // 1 -> 9.35, 2 -> 9.27, 3 -> 9.24, 5 -> 9.23, 7 -> 9.21, 9 -> 9.22, 11 -> 9.31, 17 -> 9.22
-  cg->rot_step = 5;
+  cg->rot_step = RG_COMPACT_ROTATION;
+  cg->grp0 = 0;
   return true;
 }
 
@@ -485,21 +496,32 @@ namespace {
 template <typename IndT>
 __global__ __launch_bounds__(256) void compact_pack_kernel(const IndT* __restrict__ indptr,
                                                             const uint16_t* __restrict__ lidx,
-                                                            const float* __restrict__ wts, ChunkGrid cg, long n_seg,
-                                                            const int64_t* __restrict__ rec_ptr, unsigned w_base,
-                                                            rg_u32x4* __restrict__ rec, int32_t* __restrict__ error_flag) {
+                                                            const float* __restrict__ wts, ChunkGrid cg, long n_slots,
+                                                            int rec_order, const int64_t* __restrict__ rec_ptr,
+                                                            unsigned w_base, rg_u32x4* __restrict__ rec,
+                                                            int32_t* __restrict__ error_flag) {
   const int lane = threadIdx.x & 63;
-  const long seg = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (seg >= n_seg) return;
-  const long line = seg / cg.nsx;
-  const unsigned sx = (unsigned)(seg - line * cg.nsx);
-  const unsigned x0 = sx * cg.seg_base + (sx < cg.seg_extra ? sx : cg.seg_extra);
-  const long r0 = line * cg.line_len + x0;
-  const int nrows = (int)(cg.seg_base + (sx < cg.seg_extra ? 1u : 0u));
-  const long p0 = (long)indptr[r0], p1 = (long)indptr[r0 + nrows];
-  const long rb = rec_ptr[seg], rn = rec_ptr[seg + 1] - rb;
+  const long slot = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (slot >= n_slots) return;
+  long r0;
+  int nrows;
+  if (rec_order == RG_REC_ORDER_DISPATCH) {      // slot = block * H + wavefront: the segment that wavefront reads
+    const unsigned bid = (unsigned)(slot / kH);
+    const Segment sg = chunk_segment(cg, block_chunk(cg, bid), (int)(slot - (long)bid * kH));
+    r0 = sg.r0;
+    nrows = sg.nrows;
+  } else {                                       // slot = segment number, line-major
+    const long line = slot / cg.nsx;
+    const unsigned sx = (unsigned)(slot - line * cg.nsx);
+    const unsigned x0 = sx * cg.seg_base + (sx < cg.seg_extra ? sx : cg.seg_extra);
+    r0 = line * cg.line_len + x0;
+    nrows = (int)(cg.seg_base + (sx < cg.seg_extra ? 1u : 0u));
+  }
+  const long p0 = nrows ? (long)indptr[r0] : 0, p1 = nrows ? (long)indptr[r0 + nrows] : 0;
+  const long rb = rec_ptr[slot], rn = rec_ptr[slot + 1] - rb;
   if (lane == 0 && rn != (p1 - p0 + 2) / 3) atomicOr(error_flag, 1);
   if (lane == 0 && rn >= (1L << 27)) atomicOr(error_flag, 4);   // the apply kernels use 32-bit byte offsets per segment
+  if (rn != (p1 - p0 + 2) / 3) return;           // never write outside the records rec_ptr gives this segment
   for (long r = lane; r < rn; r += 64) {
     unsigned code[3], pos[3];
 #pragma unroll
@@ -527,9 +549,11 @@ __global__ __launch_bounds__(256) void compact_pack_kernel(const IndT* __restric
 
 extern "C" int rg_csr_compact_pack(const void* indptr, int32_t indptr_is_i64, const uint16_t* local_idx,
                                    const float* weights, int64_t n_rows, int64_t line_len, int64_t lines_per_plane,
-                                   const int64_t* rec_ptr, uint32_t w_base, void* records, int32_t* error_flag,
-                                   rg_stream_t stream) {
-  RG_REQUIRE(n_rows >= 0, RG_EINVAL, "rg_csr_compact_pack: negative size");
+                                   const int64_t* rec_ptr, int32_t rec_order, int64_t plane0, uint32_t w_base,
+                                   void* records, int32_t* error_flag, rg_stream_t stream) {
+  RG_REQUIRE(n_rows >= 0 && plane0 >= 0, RG_EINVAL, "rg_csr_compact_pack: negative size");
+  RG_REQUIRE(rec_order == RG_REC_ORDER_SEGMENT || rec_order == RG_REC_ORDER_DISPATCH, RG_EINVAL,
+             "rg_csr_compact_pack: rec_order=%d is neither RG_REC_ORDER_SEGMENT nor RG_REC_ORDER_DISPATCH", rec_order);
   if (n_rows == 0) return RG_OK;
   RG_REQUIRE(indptr && rec_ptr && error_flag, RG_EINVAL, "rg_csr_compact_pack: null pointer");
   RG_REQUIRE(rg::aligned16(records), RG_EALIGN, "rg_csr_compact_pack: records must be 16-byte aligned");
@@ -537,17 +561,20 @@ extern "C" int rg_csr_compact_pack(const void* indptr, int32_t indptr_is_i64, co
   RG_REQUIRE(make_chunk_grid(n_rows, line_len, lines_per_plane, &cg), RG_EINVAL,
              "rg_csr_compact_pack: n_rows=%ld is not planes x lines_per_plane=%ld x line_len=%ld", (long)n_rows,
              (long)lines_per_plane, (long)line_len);
-  const long n_seg = cg.n_planes * cg.lines_per_plane * (long)cg.nsx;
-  const long blocks = (n_seg + 3) / 4;
+  RG_REQUIRE(chunk_count(cg) <= 0x7FFFFFFFL / kH, RG_EUNSUPPORTED, "rg_csr_compact_pack: too many chunks for one launch");
+  cg.grp0 = (unsigned)(((unsigned long)plane0 * cg.nyg) & 0xFFFFFFFFul);   // the rotation counts line groups mod 2^32
+  const long n_slots = rec_order == RG_REC_ORDER_DISPATCH ? chunk_count(cg) * kH
+                                                          : cg.n_planes * cg.lines_per_plane * (long)cg.nsx;
+  const long blocks = (n_slots + 3) / 4;
   RG_REQUIRE(blocks <= 0x7FFFFFFFL, RG_EUNSUPPORTED, "rg_csr_compact_pack: too many segments for one launch");
   hipStream_t s = (hipStream_t)stream;
   if (indptr_is_i64)
     hipLaunchKernelGGL(compact_pack_kernel<int64_t>, dim3((unsigned)blocks), dim3(256), 0, s,
-                       static_cast<const int64_t*>(indptr), local_idx, weights, cg, n_seg, rec_ptr, w_base,
+                       static_cast<const int64_t*>(indptr), local_idx, weights, cg, n_slots, rec_order, rec_ptr, w_base,
                        static_cast<rg_u32x4*>(records), error_flag);
   else
     hipLaunchKernelGGL(compact_pack_kernel<int32_t>, dim3((unsigned)blocks), dim3(256), 0, s,
-                       static_cast<const int32_t*>(indptr), local_idx, weights, cg, n_seg, rec_ptr, w_base,
+                       static_cast<const int32_t*>(indptr), local_idx, weights, cg, n_slots, rec_order, rec_ptr, w_base,
                        static_cast<rg_u32x4*>(records), error_flag);
   return rg::check_launch("rg_csr_compact_pack");
 }
@@ -581,17 +608,23 @@ extern "C" int rg_csr_compact_pack(const void* indptr, int32_t indptr_is_i64, co
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
 
+constexpr int kRowwiseChunksPerBlock = 1;   // consecutive chunks one workgroup takes (see the kernel: 1 measured best)
+
 template <int NF> struct RowwiseConfig;
 template <> struct RowwiseConfig<1> { static constexpr int kpre = 3, target = 4; static constexpr bool narrow = false, regs = false; };
 template <> struct RowwiseConfig<2> { static constexpr int kpre = 3, target = 4; static constexpr bool narrow = false, regs = false; };
 template <> struct RowwiseConfig<3> { static constexpr int kpre = 2, target = 6; static constexpr bool narrow = true, regs = true; };
 template <> struct RowwiseConfig<4> { static constexpr int kpre = 3, target = 8; static constexpr bool narrow = false, regs = true; };
 
-template <typename IndT, int NF, int STRIDE>
+// DIAG (timing-only diagnostics of tools/exp_placement4.py, results wrong by construction; one field only): bit 0 = the
+// window is not gathered (no dictionary / field reads), bit 1 = no output store, bit 2 / bit 3 = cache policy sc0 / nt on
+// the record loads, bit 4 = no record loads at all (the stream is replaced by a constant)
+template <typename IndT, int NF, int STRIDE, int DIAG = 0>
 __global__ __launch_bounds__(64 * kH) void csr_compact_rowwise_kernel(
     const IndT* __restrict__ indptr, const int64_t* __restrict__ dict_ptr, const int32_t* __restrict__ dict, ChunkGrid cg,
     const float* __restrict__ packed, unsigned last_gate, float fill, int window_cap, long n_vox, float* __restrict__ out,
-    const rg_u32x4* __restrict__ rec, const int64_t* __restrict__ rec_ptr, unsigned w_base, int lanes_hint) {
+    const rg_u32x4* __restrict__ rec, const int64_t* __restrict__ rec_ptr, unsigned w_base, int lanes_hint,
+    int rec_order, unsigned n_chunks, int chunks_per_block) {
   static_assert(NF >= 1 && NF <= 4 && (STRIDE == 1 || STRIDE == 2 || STRIDE == 4), "passes of 1-4 fields");
   using Cfg = RowwiseConfig<NF>;
   constexpr int KPRE = Cfg::kpre;
@@ -605,15 +638,26 @@ __global__ __launch_bounds__(64 * kH) void csr_compact_rowwise_kernel(
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   f32x2* rowacc = rowacc_all[kRegs ? 0 : wv];
+  // 26-bit weight mask in a VGPR the compiler cannot fold: (x & mask) | w_base is then ONE v_and_or_b32 (this ISA's VOP3
+  // takes no literal, and a literal mask splits it into v_and + v_or)
+  unsigned wmask = 0x3FFFFFFu;
+  asm volatile("" : "+v"(wmask));
+
+  // A workgroup takes chunks_per_block CONSECUTIVE blocks of the dispatch order, one after the other (default: 1).
+  // Round-3 experiment: the kernel's only store costs 5-15 % of the launch (tools/exp_placement4.py: 7.4 ms without it,
+  // 7.8-8.7 with it, depending on where records and grid lie in memory), and the first suspect was its acknowledgement
+  // at the end of every workgroup's life.  Letting it overlap the next chunk's work changed nothing (2 / 4 / 8 / 32
+  // chunks per workgroup: +0.1 ... +0.3 ms, the extra barrier): the cost is the memory system's, a trickle of writes
+  // among the reads (tools/exp_placement5.py reproduces it with a bare read probe).  The loop stays as the knob it is.
+  for (int cb = 0; cb < chunks_per_block; ++cb) {
+  const unsigned bid = blockIdx.x * (unsigned)chunks_per_block + (unsigned)cb;
+  if (bid >= n_chunks) break;                         // workgroup-uniform
+  if (cb > 0) __syncthreads();                        // every wavefront is done with the previous chunk's window
   float mine_p[NF], mine_w[NF];                       // kRegs: lane == row
 #pragma unroll
   for (int f = 0; f < NF; ++f) mine_p[f] = mine_w[f] = 0.0f;
 
-  const unsigned bid = blockIdx.x;           // block -> chunk: the rotation of csr_compact_kernel
-  const unsigned grp = bid / cg.nsx;
-  const unsigned col = bid - grp * cg.nsx;
-  const unsigned rot = (col + (grp * cg.rot_step) % cg.nsx);
-  const unsigned chunk = grp * cg.nsx + (rot >= cg.nsx ? rot - cg.nsx : rot);
+  const unsigned chunk = block_chunk(cg, bid);
   const long d0 = dict_ptr[chunk];
   const int nd_all = (int)(dict_ptr[chunk + 1] - d0);
   const bool split = nd_all > 65536;
@@ -634,8 +678,10 @@ __global__ __launch_bounds__(64 * kH) void csr_compact_rowwise_kernel(
   const int re_o = nrows ? (int)((long)indptr[r0 + (lane + 1 < nrows ? lane + 1 : nrows)] - seg_b) : 0;
   long rec_b = 0, rec_n = 0;
   if (nrows) {
-    rec_b = rec_ptr[sg.seg];
-    rec_n = rec_ptr[sg.seg + 1] - rec_b;
+    // dispatch order: the H segments of a workgroup's chunk are neighbours in the stream, and so are consecutive blocks
+    const long slot = rec_order == RG_REC_ORDER_DISPATCH ? (long)bid * kH + wv : sg.seg;
+    rec_b = rec_ptr[slot];
+    rec_n = rec_ptr[slot + 1] - rec_b;
   }
   const rsrc_t rr = make_rsrc(rec + rec_b, rec_n * 16);
   constexpr int kOutOfRange = 0x7FFFFFF0;            // byte offset no segment reaches: the load returns zeros
@@ -668,8 +714,13 @@ __global__ __launch_bounds__(64 * kH) void csr_compact_rowwise_kernel(
     for (int i = threadIdx.x; i <= nd_all; i += 64 * kH) {
       float v[STRIDE];
       if (i < nd_all) {
-        const unsigned g0 = (unsigned)cdict[i];
-        rg::load_packed<STRIDE>(packed, g0 < last_gate ? g0 : last_gate, v);
+        if constexpr (DIAG & 1) {
+#pragma unroll
+          for (int s = 0; s < STRIDE; ++s) v[s] = 1.0f;
+        } else {
+          const unsigned g0 = (unsigned)cdict[i];
+          rg::load_packed<STRIDE>(packed, g0 < last_gate ? g0 : last_gate, v);
+        }
       } else {
 #pragma unroll
         for (int s = 0; s < STRIDE; ++s) v[s] = __builtin_bit_cast(float, RG_EXCLUDED_BITS);
@@ -736,14 +787,12 @@ __global__ __launch_bounds__(64 * kH) void csr_compact_rowwise_kernel(
   };
   auto issue = [&](const Step& r, rg_u32x4 (&regs)[KPRE]) {
 #pragma unroll
-    for (int k = 0; k < KPRE; ++k)
-      regs[k] = rg_buffer_load_v4u32(rr, (k << lgl) < r.rem ? r.off0 + 16 * (k << lgl) : kOutOfRange, 0, 0);
+    for (int k = 0; k < KPRE; ++k) {
+      if constexpr (DIAG & 16) regs[k] = (rg_u32x4){0x3F00000u, 0x3F00000u, 0x3F00000u, (unsigned)lane};
+      else regs[k] = rg_buffer_load_v4u32(rr, (k << lgl) < r.rem ? r.off0 + 16 * (k << lgl) : kOutOfRange, 0,
+                                          (DIAG & 4) ? 1 : (DIAG & 8) ? 2 : 0);
+    }
   };
-  // 26-bit weight mask in a VGPR the compiler cannot fold: (x & mask) | w_base is then ONE v_and_or_b32 (this ISA's VOP3
-  // takes no literal, and a literal mask splits it into v_and + v_or)
-  unsigned wmask = 0x3FFFFFFu;
-  asm volatile("" : "+v"(wmask));
-
   auto run = [&](auto wtag) {
     constexpr bool kWindowed = decltype(wtag)::value;
     float ap[NF], aw[NF];                           // the running sums of the lane's row, across the round's steps
@@ -861,25 +910,51 @@ __global__ __launch_bounds__(64 * kH) void csr_compact_rowwise_kernel(
       f32x2 s = (f32x2)(0.0f);
       if constexpr (kRegs) s = (f32x2){mine_p[f], mine_w[f]};
       else if (span > 0) s = rowacc[lane * NF + f];
-      out[(size_t)f * n_vox + r0 + lane] = s.y > 0.0f ? (float)((double)s.x / (double)s.y) : fill;
+      if constexpr (DIAG & 2) {
+        if (s.x == 123.456f) out[(size_t)f * n_vox + r0 + lane] = s.y;       // practically never
+      } else if constexpr (DIAG & 32) {      // dense, dispatch-ordered store: 1 KiB per workgroup, neighbours adjacent
+        const long idx = ((long)bid * kH + wv) * 64 + lane;
+        if (idx < n_vox) out[idx] = s.y > 0.0f ? (float)((double)s.x / (double)s.y) : fill;
+      } else if constexpr (DIAG & 128) {     // non-temporal store
+        __builtin_nontemporal_store(s.y > 0.0f ? (float)((double)s.x / (double)s.y) : fill, &out[(size_t)f * n_vox + r0 + lane]);
+      } else if constexpr (DIAG & 256) {     // write-through store (sc0 sc1)
+        const float val = s.y > 0.0f ? (float)((double)s.x / (double)s.y) : fill;
+        float* dst = &out[(size_t)f * n_vox + r0 + lane];
+        asm volatile("global_store_dword %0, %1, off sc0 sc1" : : "v"(dst), "v"(val) : "memory");
+      } else if constexpr (DIAG & 512) {     // sc1 only
+        const float val = s.y > 0.0f ? (float)((double)s.x / (double)s.y) : fill;
+        float* dst = &out[(size_t)f * n_vox + r0 + lane];
+        asm volatile("global_store_dword %0, %1, off sc1" : : "v"(dst), "v"(val) : "memory");
+      } else if constexpr (DIAG & 64) {      // grid layout, but only the 128-byte lines this wavefront owns entirely
+        const long a = r0 + lane, lo = (r0 + 31) & ~31L, hi = (r0 + nrows) & ~31L;
+        if (a >= lo && a < hi) out[a] = s.y > 0.0f ? (float)((double)s.x / (double)s.y) : fill;
+      } else {
+        out[(size_t)f * n_vox + r0 + lane] = s.y > 0.0f ? (float)((double)s.x / (double)s.y) : fill;
+      }
     }
   }
+  }   // chunks of this workgroup
 }
 
-template <typename IndT, int NF>
+template <typename IndT, int NF, int DIAG = 0>
 int launch_rowwise(int window_cap, const void* indptr, const int64_t* dict_ptr, const int32_t* dict, const ChunkGrid& cg,
                    long n_vox, const float* packed, long n_gates, float fill, float* out, hipStream_t s,
-                   const PackedStream& ps, int lanes_hint) {
+                   const PackedStream& ps, int lanes_hint, int chunks_per_block = 0) {
   constexpr int STRIDE = stride_for(NF);
   constexpr int WS = RowwiseConfig<NF>::narrow ? 3 : NF == 1 ? 2 : STRIDE;        // floats per window entry
   constexpr long kStatic = RowwiseConfig<NF>::regs ? 16 : (long)kH * 64 * NF * 8;   // the row-sum array, if any
   // one entry beyond window_cap: the sentinel; a smaller window only sends more chunks down the per-pair path
   const long room = (65536 - kStatic - 256) / (4 * WS) - 1;
   if (window_cap > room) window_cap = (int)room;
-  hipLaunchKernelGGL((csr_compact_rowwise_kernel<IndT, NF, STRIDE>), dim3((unsigned)chunk_count(cg)), dim3(64 * kH),
+  const long n_chunks = chunk_count(cg);
+  if (chunks_per_block <= 0) chunks_per_block = kRowwiseChunksPerBlock;
+  // never fewer workgroups than fill the chip a few times over: small grids keep one chunk per workgroup
+  while (chunks_per_block > 1 && n_chunks / chunks_per_block < 8192) chunks_per_block >>= 1;
+  hipLaunchKernelGGL((csr_compact_rowwise_kernel<IndT, NF, STRIDE, DIAG>),
+                     dim3((unsigned)((n_chunks + chunks_per_block - 1) / chunks_per_block)), dim3(64 * kH),
                      ((size_t)(window_cap + 1) * WS * sizeof(float) + 15) / 16 * 16, s, static_cast<const IndT*>(indptr),
                      dict_ptr, dict, cg, packed, (unsigned)(n_gates - 1), fill, window_cap, n_vox, out, ps.rec, ps.rec_ptr,
-                     ps.w_base, lanes_hint);
+                     ps.w_base, lanes_hint, ps.order, (unsigned)n_chunks, chunks_per_block);
   return rg::check_launch("rg_csr_compact_apply_packed_f32");
 }
 
@@ -888,7 +963,26 @@ int launch_rowwise_nf(int nf, int window_cap, const void* indptr, const int64_t*
                       const ChunkGrid& cg, long n_vox, const float* packed, long n_gates, float fill, float* out,
                       hipStream_t s, const PackedStream& ps, int lanes_hint) {
 #define RG_ROW(NF_) \
-  launch_rowwise<IndT, NF_>(window_cap, indptr, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s, ps, lanes_hint)
+  launch_rowwise<IndT, NF_>(window_cap, indptr, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s, ps, lanes_hint, cpb)
+  int cpb = 0;
+  if (lanes_hint >= 200 && lanes_hint <= 264) {                // tile = 2200 + n: n consecutive chunks per workgroup
+    cpb = lanes_hint - 200;
+    lanes_hint = 0;
+  }
+  if (nf == 1 && lanes_hint >= 100 && lanes_hint < 200) {      // timing-only diagnostics (tile = 2100 + DIAG bits)
+    const int cpb1 = 1;          // the diagnostics run one chunk per workgroup
+#define RG_DIAG(D_) \
+  case D_: return launch_rowwise<IndT, 1, D_>(window_cap, indptr, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s, ps, 0, cpb1)
+    switch (lanes_hint - 100) {
+      RG_DIAG(1); RG_DIAG(2); RG_DIAG(3); RG_DIAG(4); RG_DIAG(8); RG_DIAG(16); RG_DIAG(17); RG_DIAG(19); RG_DIAG(32);
+      RG_DIAG(64);
+      case 70: return launch_rowwise<IndT, 1, 128>(window_cap, indptr, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s, ps, 0, cpb1);
+      case 71: return launch_rowwise<IndT, 1, 256>(window_cap, indptr, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s, ps, 0, cpb1);
+      case 72: return launch_rowwise<IndT, 1, 512>(window_cap, indptr, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s, ps, 0, cpb1);
+      default: break;
+    }
+#undef RG_DIAG
+  }
   switch (nf) {
     case 1: return RG_ROW(1);
     case 2: return RG_ROW(2);
@@ -905,7 +999,8 @@ int launch_rowwise_nf(int nf, int window_cap, const void* indptr, const int64_t*
 // tile = 2000 + h: row-wise with a diagnostic lane split (h = 1..64: that many lanes per row; h = 70 + t: aim for t
 // records per lane and row) -- a different split is a different order of the float32 adds.
 extern "C" int rg_csr_compact_apply_packed_f32(const void* indptr, int32_t indptr_is_i64, const void* records,
-                                               const int64_t* rec_ptr, uint32_t w_base, const int64_t* dict_ptr,
+                                               const int64_t* rec_ptr, int32_t rec_order, uint32_t w_base,
+                                               const int64_t* dict_ptr,
                                                const int32_t* dict, int64_t n_vox, int64_t n_pairs, int64_t line_len,
                                                int64_t lines_per_plane, const float* packed, int32_t n_fields,
                                                int32_t stride, int64_t n_gates, float fill_value, float* out,
@@ -914,10 +1009,13 @@ extern "C" int rg_csr_compact_apply_packed_f32(const void* indptr, int32_t indpt
   const int lanes_hint = tile >= 2000 ? tile - 2000 : 0;
   RG_REQUIRE(tile == 0 || tile == 384 || ((tile == 576 || tile == 768) && n_fields == 1) ||
                  (tile >= 2000 && ((lanes_hint >= 1 && lanes_hint <= 64 && (lanes_hint & (lanes_hint - 1)) == 0) ||
-                                   (lanes_hint > 70 && lanes_hint <= 99))),
+                                   (lanes_hint > 70 && lanes_hint <= 99) || (lanes_hint >= 100 && lanes_hint < 200) ||
+                                   (lanes_hint >= 201 && lanes_hint <= 264))),
              RG_EINVAL,
              "rg_csr_compact_apply_packed_f32: tile must be 0 (row-wise kernel), 384 (tile kernel; one field: also 576 / "
              "768) or 2000 + lane split");
+  RG_REQUIRE(rec_order == RG_REC_ORDER_SEGMENT || rec_order == RG_REC_ORDER_DISPATCH, RG_EINVAL,
+             "rg_csr_compact_apply_packed_f32: rec_order=%d is neither RG_REC_ORDER_SEGMENT nor RG_REC_ORDER_DISPATCH", rec_order);
   RG_REQUIRE(n_fields >= 1 && n_fields <= 4, RG_EUNSUPPORTED,
              "rg_csr_compact_apply_packed_f32: n_fields=%d not in 1..4 (5-8 fields use 128-pair tiles, not a whole number "
              "of 64-record loads)", n_fields);
@@ -944,6 +1042,7 @@ extern "C" int rg_csr_compact_apply_packed_f32(const void* indptr, int32_t indpt
   ps.rec = static_cast<const rg_u32x4*>(records);
   ps.rec_ptr = rec_ptr;
   ps.w_base = w_base;
+  ps.order = rec_order;
   hipStream_t s = (hipStream_t)stream;
   if (rowwise)
     return indptr_is_i64 ? launch_rowwise_nf<int64_t>(n_fields, window_cap, indptr, dict_ptr, dict, cg, n_vox, packed, n_gates,

@@ -210,18 +210,16 @@ def _build_compact_only(search: "RoiSearch", weighting: str, pairs_per_slab: int
         weights = local = rec = rec_ptr = None
         w_base = 0
         if packed:
-            starts = torch.tensor(CompactCSR.segment_starts(nx), device=dev, dtype=torch.int64)
-            line0 = torch.arange(nz * ny, device=dev, dtype=torch.int64) * nx
-            edges = indptr[(line0[:, None] + starts[None, :]).reshape(-1)].view(nz * ny, -1)
-            n_rec_seg = ((edges[:, 1:] - edges[:, :-1]) + 2) // 3
-            nsx = n_rec_seg.shape[1]
-            rec_ptr = torch.zeros(n_rec_seg.numel() + 1, dtype=torch.int64, device=dev)
-            rec_ptr[1:] = torch.cumsum(n_rec_seg.reshape(-1), 0)
+            from . import grid_geometry
+            rec_order = grid_geometry.DEFAULT_REC_ORDER
+            rec_ptr = CompactCSR.record_pointers(indptr, search.grid_shape, rec_order)
+            if rec_ptr is None:
+                return None
+            slots_per_plane = (rec_ptr.numel() - 1) // nz      # chunks never cross a plane: neither do the slots
             n_rec = int(rec_ptr[-1])
             rec = torch.empty((max(n_rec, 1), 4), dtype=torch.int32, device=dev)[:n_rec]
             w_base = _PACK_BASE_EXPONENT[weighting] << 23
             err = torch.zeros(1, dtype=torch.int32, device=dev)
-            del edges, n_rec_seg, line0
         else:
             weights = torch.empty(max(n_pairs, 1), dtype=torch.float32, device=dev)[:n_pairs]
             local = torch.empty(max(n_pairs, 1), dtype=torch.int16, device=dev)[:n_pairs]
@@ -256,11 +254,10 @@ def _build_compact_only(search: "RoiSearch", weighting: str, pairs_per_slab: int
             count_parts.append(built[0])
             dict_parts.append(built[1])
             if packed and p1 > p0:
-                seg0 = iz0 * ny * nsx
                 _native.check(lib.rg_csr_compact_pack(
                     _native.ptr(indptr) + 8 * iz0 * n_xy, 1, l_ptr, w_ptr, (iz1 - iz0) * n_xy, nx, ny,
-                    _native.ptr(rec_ptr) + 8 * seg0, w_base, _native.ptr(rec), _native.ptr(err), stream),
-                    "rg_csr_compact_pack")
+                    _native.ptr(rec_ptr) + 8 * iz0 * slots_per_plane, rec_order, iz0, w_base, _native.ptr(rec),
+                    _native.ptr(err), stream), "rg_csr_compact_pack")
                 if int(err.item()):
                     logger.info(f"rg_csr_compact_pack flag {int(err.item())} (a weight outside the 26-bit code, or an over-long "
                                 "segment): keeping the plain compact layout instead")
@@ -271,7 +268,7 @@ def _build_compact_only(search: "RoiSearch", weighting: str, pairs_per_slab: int
         counts_all = torch.cat(count_parts) if count_parts else torch.zeros(0, dtype=torch.int64, device=dev)
         compact = CompactCSR._finish(indptr, search.grid_shape, local, counts_all, dict_parts)
         if packed:
-            compact.rec, compact.rec_ptr, compact.w_base = rec, rec_ptr, w_base
+            compact.rec, compact.rec_ptr, compact.rec_order, compact.w_base = rec, rec_ptr, rec_order, w_base
         if n_pairs <= _INT32_MAX:
             indptr = indptr.to(torch.int32)
     return DeviceCSR(indptr, None, weights, max_gate, n_pairs=n_pairs), compact

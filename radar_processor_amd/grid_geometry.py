@@ -22,6 +22,11 @@ logger = logging.getLogger("radar_grid.geometry")  # same logger name as the ref
 _INT32_MAX = np.iinfo(np.int32).max
 _NOT_COMPACTABLE = 0x40000000     # chunk_counts marker of rg_csr_compact_count
 
+# Order in which the packed records of a geometry are stored (include/radargrid_hip.h: RG_REC_ORDER_*).  DISPATCH = the
+# order in which the apply kernels' workgroups read them, so that a launch sweeps the array as one moving front;
+# SEGMENT = line-major segments (round 2's layout, kept for A/B measurements: bench.py --rec-order segment).
+DEFAULT_REC_ORDER = _native.RG_REC_ORDER_DISPATCH
+
 
 class DeviceCSR:
     """CSR arrays resident in HBM (torch tensors used purely as allocations)."""
@@ -52,7 +57,7 @@ class CompactCSR:
     above 65536.  ``indptr`` and ``weights`` are shared with the standard CSR."""
 
     __slots__ = ("local_idx", "dict_ptr", "dict", "n_dict", "max_dict", "window_cap", "grid_shape", "chunk_pairs",
-                 "chunk_counts", "rec", "rec_ptr", "w_base", "_pack_tried")
+                 "chunk_counts", "rec", "rec_ptr", "rec_order", "w_base", "_pack_tried")
 
     def __init__(self, local_idx, dict_ptr, dict_, max_dict: int, window_cap: int, grid_shape, chunk_pairs=None,
                  chunk_counts=None):
@@ -67,7 +72,8 @@ class CompactCSR:
         self.chunk_counts = chunk_counts    # int64 [chunks]: distinct gates     } given field count (window_for)
         # packed pair stream for passes of 1-4 fields (ensure_packed): 16-byte records of three pairs, or None
         self.rec = None                     # int32 [n_rec, 4]
-        self.rec_ptr = None                 # int64 [segments + 1]
+        self.rec_ptr = None                 # int64 [slots + 1]: records of the segment in slot s (see rec_order)
+        self.rec_order = DEFAULT_REC_ORDER  # RG_REC_ORDER_SEGMENT (slot = segment) / RG_REC_ORDER_DISPATCH (slot_of_segments)
         self.w_base = 0                     # weight code = float32 bits - w_base
         self._pack_tried = False
 
@@ -106,29 +112,68 @@ class CompactCSR:
                         "of 8, the compact copy keeps the plain arrays")
             return False
         nz, ny, nx = self.grid_shape
-        starts = torch.tensor(self.segment_starts(nx), device=dev, dtype=torch.int64)
-        line0 = torch.arange(nz * ny, device=dev, dtype=torch.int64) * nx
-        edges = csr.indptr[(line0[:, None] + starts[None, :]).reshape(-1)].to(torch.int64).view(nz * ny, -1)
-        n_rec_seg = ((edges[:, 1:] - edges[:, :-1]) + 2) // 3
-        if int(n_rec_seg.max()) >= 1 << 27:      # the kernels address a segment's records with 32-bit byte offsets
+        rec_ptr = self.record_pointers(csr.indptr, self.grid_shape, self.rec_order)
+        if rec_ptr is None:                      # the kernels address a segment's records with 32-bit byte offsets
             logger.info("a segment holds more than 2^27 records: the compact copy keeps the plain arrays")
             return False
-        rec_ptr = torch.zeros(n_rec_seg.numel() + 1, dtype=torch.int64, device=dev)
-        rec_ptr[1:] = torch.cumsum(n_rec_seg.reshape(-1), 0)
         n_rec = int(rec_ptr[-1])
         rec = torch.empty((max(n_rec, 1), 4), dtype=torch.int32, device=dev)[:n_rec]
         err = torch.zeros(1, dtype=torch.int32, device=dev)
         w_base = base << 23
         with torch.cuda.device(dev):
             _native.check(lib.rg_csr_compact_pack(_native.ptr(csr.indptr), int(csr.is_i64), _native.ptr(self.local_idx),
-                                                  _native.ptr(csr.weights), csr.n_vox, nx, ny, _native.ptr(rec_ptr), w_base,
-                                                  _native.ptr(rec), _native.ptr(err), _native.stream_ptr()),
+                                                  _native.ptr(csr.weights), csr.n_vox, nx, ny, _native.ptr(rec_ptr),
+                                                  self.rec_order, 0, w_base, _native.ptr(rec), _native.ptr(err),
+                                                  _native.stream_ptr()),
                           "rg_csr_compact_pack")
         if int(err.item()):
             raise _native.NativeError(f"rg_csr_compact_pack reported flag {int(err.item())}")
         self.rec, self.rec_ptr, self.w_base = rec, rec_ptr, w_base
         logger.info(f"Packed pair stream: {rec.numel() * 4 / 1e6:.1f} MB ({16 * n_rec / csr.n_pairs:.2f} bytes per pair)")
         return True
+
+    @classmethod
+    def slot_of_segments(cls, line, sx, grid_shape, rec_order: int):
+        """Slot (index into ``rec_ptr``) of segment ``sx`` of grid line ``line`` (int64 tensors, lines counted through all
+        planes).  ``RG_REC_ORDER_SEGMENT``: the line-major segment number.  ``RG_REC_ORDER_DISPATCH``: ``block * H + w``
+        for the wavefront ``w`` of the workgroup ``block`` that reads the segment -- the inverse of the kernels'
+        block -> chunk rotation (``block_chunk`` in csrc/rg_csr_compact.hip, 32-bit unsigned arithmetic)."""
+        nz, ny, nx = (int(v) for v in grid_shape)
+        nsx, nyg, _ = cls.layout(grid_shape)
+        if rec_order == _native.RG_REC_ORDER_SEGMENT:
+            return line * nsx + sx
+        lines = _native.RG_COMPACT_LINES
+        plane = line // ny
+        y = line - plane * ny
+        grp = plane * nyg + y // lines
+        shift = ((grp * _native.RG_COMPACT_ROTATION) & 0xFFFFFFFF) % nsx
+        col = (sx - shift) % nsx                     # the block column whose rotated column is sx
+        return (grp * nsx + col) * lines + y % lines
+
+    @classmethod
+    def record_pointers(cls, indptr, grid_shape, rec_order: int):
+        """``rec_ptr`` (int64 ``[slots + 1]``) for the row pointers of a whole grid: every segment gets
+        ``ceil(pairs / 3)`` records, laid out in slot order.  ``None`` when a segment would hold 2^27 records or more."""
+        torch = _native.torch_mod()
+        dev = indptr.device
+        nz, ny, nx = (int(v) for v in grid_shape)
+        nsx, nyg, n_chunks = cls.layout(grid_shape)
+        starts = torch.tensor(cls.segment_starts(nx), device=dev, dtype=torch.int64)
+        line0 = torch.arange(nz * ny, device=dev, dtype=torch.int64) * nx
+        edges = indptr[(line0[:, None] + starts[None, :]).reshape(-1)].to(torch.int64).view(nz * ny, nsx + 1)
+        n_rec_seg = ((edges[:, 1:] - edges[:, :-1]) + 2) // 3
+        if n_rec_seg.numel() and int(n_rec_seg.max()) >= 1 << 27:
+            return None
+        if rec_order == _native.RG_REC_ORDER_SEGMENT:
+            per_slot = n_rec_seg.reshape(-1)
+        else:
+            line = torch.arange(nz * ny, device=dev, dtype=torch.int64)[:, None].expand(nz * ny, nsx)
+            sx = torch.arange(nsx, device=dev, dtype=torch.int64)[None, :].expand(nz * ny, nsx)
+            per_slot = torch.zeros(n_chunks * _native.RG_COMPACT_LINES, dtype=torch.int64, device=dev)
+            per_slot[cls.slot_of_segments(line, sx, grid_shape, rec_order).reshape(-1)] = n_rec_seg.reshape(-1)
+        rec_ptr = torch.zeros(per_slot.numel() + 1, dtype=torch.int64, device=dev)
+        rec_ptr[1:] = torch.cumsum(per_slot, 0)
+        return rec_ptr
 
     @staticmethod
     def layout(grid_shape):
@@ -287,7 +332,7 @@ class CompactCSR:
         x = rows - line * nx
         split = extra * (base + 1)
         sx = (x // (base + 1)).where(x < split, extra + (x - split) // max(base, 1))
-        seg = line * nsx + sx
+        seg = self.slot_of_segments(line, sx, self.grid_shape, self.rec_order)
         x0 = (sx * base + torch.minimum(sx, torch.full_like(sx, extra)))
         seg_first_pair = csr.indptr[line * nx + x0].to(torch.int64)            # pair offset where the row's segment starts
         lens = ip[1:] - ip[:-1]

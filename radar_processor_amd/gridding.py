@@ -164,7 +164,7 @@ class CsrGridder:
                                                                 or csr.weights is None):
             c = self.compact
             _native.check(self.lib.rg_csr_compact_apply_packed_f32(
-                _native.ptr(csr.indptr), int(csr.is_i64), _native.ptr(c.rec), _native.ptr(c.rec_ptr), c.w_base,
+                _native.ptr(csr.indptr), int(csr.is_i64), _native.ptr(c.rec), _native.ptr(c.rec_ptr), c.rec_order, c.w_base,
                 _native.ptr(c.dict_ptr), _native.ptr(c.dict), self.n_vox, csr.n_pairs, nx, ny, _native.ptr(self.packed),
                 self.n_fields, self.stride, self.n_gates, float(np.float32(fill_value)), _native.ptr(out), self.window,
                 self.tile if (self.tile in (384, 576, 768) or self.tile >= 2000) else 0, _native.stream_ptr()),

@@ -288,13 +288,37 @@ def gen_g8(ref, synth):
     print("g8", same, ref_keys == our_keys)
 
 
+def gen_g9(ref, synth):
+    """a1, the part the reference itself can pin: the HEIGHT of a gate.  The reference's gate coordinates are PyART's
+    (absent), but ``products.compute_beam_height`` (products.py:70-89) evaluates the same 4/3-earth height
+    ``sqrt(r^2 + (ke*Re)^2 + 2*r*ke*Re*sin(el)) - ke*Re`` with the same constants (products.py:19-20) from a GROUND
+    distance it first turns back into a slant range, ``s / max(cos(el), 0.01)``.  Fed ``s = r*cos(el)`` it therefore
+    returns the z of the gate at slant range r (float64); stored for every sweep elevation and the range tables of
+    BASELINE configs 1, 2 and 4.  x / y stay unpinned (PyART's arc-length formula has no counterpart in the tree)."""
+    out = {}
+    tables = {}
+    for tag, (n_elev, n_gates) in dict(c1=(1, 500), c2=(12, 1000), c4=(14, 2000)).items():
+        elev, _, rng_m = synth.sweep_geometry(n_elev, 4, n_gates)
+        elev = np.asarray(elev, dtype=np.float64)
+        rng_m = np.asarray(rng_m, dtype=np.float64)
+        z = np.stack([ref.products.compute_beam_height(rng_m * np.cos(np.radians(e)), float(e), 0.0) for e in elev])
+        assert z.dtype == np.float64 and z.shape == (n_elev, n_gates)
+        out[f"z_{tag}"] = z
+        tables[tag] = dict(n_elev=n_elev, n_gates=n_gates, elevations=[float(e) for e in elev],
+                           first_range=float(rng_m[0]), range_step=float(rng_m[1] - rng_m[0]))
+    out["meta"] = meta_blob(case="G9", tables=tables, radar_altitude=0.0,
+                            what="reference products.compute_beam_height(r*cos(el), el, 0.0), float64")
+    np.savez_compressed(os.path.join(HERE, "g9_beam_z.npz"), **out)
+    print("g9", {k: v.shape for k, v in out.items() if k != "meta"})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None)
     args = ap.parse_args()
     ref = load_reference()
     from radar_processor_amd import synthetic as synth
-    gens = dict(g2=gen_g2, g3=gen_g3, g4=gen_g4, g5=gen_g5, g6=gen_g6, g7=gen_g7, g8=gen_g8)
+    gens = dict(g2=gen_g2, g3=gen_g3, g4=gen_g4, g5=gen_g5, g6=gen_g6, g7=gen_g7, g8=gen_g8, g9=gen_g9)
     for name, fn in gens.items():
         if args.only and name not in args.only:
             continue

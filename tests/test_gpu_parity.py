@@ -468,6 +468,23 @@ def test_antenna_transform_kernel_vs_oracle_parity_unpinned(rg):
             np.testing.assert_allclose(got, other, rtol=1e-6, atol=1e-3)
 
 
+def test_antenna_transform_z_pinned_by_reference_beam_height_xy_unpinned(rg):
+    """a1, the part a reference-held vector CAN pin: z of ``rg_antenna_to_cartesian_f32`` against the reference's own
+    ``products.compute_beam_height(r*cos(el), el, 0)`` (products.py:70-89; tests/golden/g9_beam_z.npz, made by importing
+    the reference) for every elevation and range of BASELINE configs 1, 2 and 4: <= 1 float32 ulp.  x and y remain
+    **parity unpinned** (PyART's arc-length formula has no counterpart in /root/reference)."""
+    from radar_processor_amd import synthetic
+    from test_oracle_golden import _g9_tables
+    for tag, elev, rng_m, z_ref in _g9_tables():
+        az = np.array([0.0, 90.0, 181.5, 359.0])
+        _, _, z = synthetic.gate_coordinates_device(elev, az, rng_m)
+        z = z.cpu().numpy().reshape(len(elev), len(az), len(rng_m))
+        want = np.broadcast_to(z_ref.astype(np.float32)[:, None, :], z.shape)
+        ulp = np.abs(z.view(np.int32).astype(np.int64) - np.ascontiguousarray(want).view(np.int32).astype(np.int64))
+        assert ulp.max() <= 1, (tag, int(ulp.max()))
+        assert (ulp == 0).mean() > 0.99, tag          # a 1-ulp difference is a double rounding, not the rule
+
+
 def test_reference_written_npz_grids_on_gpu(rg):
     """geometry.py:121-150: the `.npz` the REFERENCE's save_geometry wrote (tests/golden/g8_ref_saved_geometry.npz)
     loaded by this build's load_geometry and gridded by the HIP path, against the grid the reference computed."""

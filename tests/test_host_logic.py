@@ -5,6 +5,7 @@ and that the product path refuses to run without a HIP device instead of falling
 Modelled on the reference's tests/test_radar_grid_geometry.py and tests/test_radar_grid_filters.py.
 """
 import ctypes
+import json
 import os
 import re
 from types import SimpleNamespace
@@ -331,6 +332,22 @@ class TestBenchLauncher:
         res = self._run(["--gpus", "4"], dict(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"))
         assert res.returncode == 2 and b"WORLD_SIZE=1 but --gpus 4" in res.stderr and not res.stdout.strip()
 
+    def test_launcher_failure_path(self):
+        """A rank that dies before the rendezvous must not leave its siblings (and the parent) waiting for the
+        process-group timeout: the launcher stops them and returns non-zero within seconds, without a JSON line."""
+        import time
+        t0 = time.time()
+        res = self._run(["--gpus", "2", "--share-device", "--rendezvous-only", "--fail-rank", "1", "--pg-timeout", "300"], {})
+        took = time.time() - t0
+        assert res.returncode != 0 and not res.stdout.strip(), res.stderr[-600:]
+        assert b"rank 1 exited with code 3: stopping the other ranks" in res.stderr
+        assert took < 30, f"launcher needed {took:.0f} s to notice a dead rank"
+
+    def test_launcher_passes_rank0_line_through(self):
+        res = self._run(["--gpus", "2", "--share-device", "--rendezvous-only"], {})
+        assert res.returncode == 0, res.stderr[-600:]
+        assert json.loads(res.stdout.decode().strip().splitlines()[-1]) == {"rendezvous": "ok", "n_gpus": 2}
+
     def test_parent_refuses_more_ranks_than_gpus(self):
         import torch
         if torch.cuda.device_count() >= 8:
@@ -369,6 +386,51 @@ class TestCompactLayoutHostLogic:
                 for sx in range(3):
                     want = (z * 2 + y // 4) * 3 + sx
                     assert bool((chunk[z, y, sx * 50:(sx + 1) * 50] == want).all())
+
+    def test_dispatch_order_slots_invert_the_block_rotation(self):
+        """RG_REC_ORDER_DISPATCH: slot = block * H + wavefront for the block -> chunk rotation of the apply kernels
+        (block_chunk in csrc/rg_csr_compact.hip), restated here in plain Python; every segment gets exactly one slot,
+        the slots of one workgroup are neighbours, and record_pointers lays the records out in slot order."""
+        import torch
+        from radar_processor_amd.grid_geometry import CompactCSR
+        H, rot = _native.RG_COMPACT_LINES, _native.RG_COMPACT_ROTATION
+        for shape in ((1, 1, 1), (3, 17, 29), (2, 6, 150), (2, 9, 700), (3, 8, 2000), (1, 4, 64)):
+            nz, ny, nx = shape
+            nsx, nyg, n_chunks = CompactCSR.layout(shape)
+            want = {}
+            for bid in range(n_chunks):                       # the kernel's map, forwards
+                grp, col = divmod(bid, nsx)
+                sx = (col + ((grp * rot) & 0xFFFFFFFF) % nsx) % nsx
+                plane, yg = divmod(grp, nyg)
+                for w in range(H):
+                    y = yg * H + w
+                    if y < ny:
+                        want[(plane * ny + y, sx)] = bid * H + w
+            line = torch.arange(nz * ny)[:, None].expand(nz * ny, nsx)
+            sx = torch.arange(nsx)[None, :].expand(nz * ny, nsx)
+            got = CompactCSR.slot_of_segments(line, sx, shape, _native.RG_REC_ORDER_DISPATCH)
+            assert got.shape == (nz * ny, nsx) and len(want) == nz * ny * nsx
+            assert all(int(got[l, s]) == v for (l, s), v in want.items())
+            assert len(set(got.reshape(-1).tolist())) == got.numel()          # one slot per segment
+            seg = CompactCSR.slot_of_segments(line, sx, shape, _native.RG_REC_ORDER_SEGMENT)
+            assert torch.equal(seg, line * nsx + sx)
+            # record_pointers: ceil(pairs / 3) records per segment, in slot order, empty slots past a plane's last line
+            rng = np.random.default_rng(nx)
+            lens = rng.integers(0, 9, nz * ny * nx)
+            indptr = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int64))
+            st = CompactCSR.segment_starts(nx)
+            for order in (_native.RG_REC_ORDER_SEGMENT, _native.RG_REC_ORDER_DISPATCH):
+                rp = CompactCSR.record_pointers(indptr, shape, order)
+                slots = CompactCSR.slot_of_segments(line, sx, shape, order)
+                assert rp.numel() == (nz * ny * nsx if order == _native.RG_REC_ORDER_SEGMENT else n_chunks * H) + 1
+                n_rec = rp[1:] - rp[:-1]
+                total = 0
+                for l in range(nz * ny):
+                    for s in range(nsx):
+                        pairs = int(indptr[l * nx + st[s + 1]] - indptr[l * nx + st[s]])
+                        assert int(n_rec[slots[l, s]]) == (pairs + 2) // 3
+                        total += (pairs + 2) // 3
+                assert int(rp[-1]) == total and int(rp[0]) == 0
 
     def test_window_choice(self):
         import torch

@@ -256,6 +256,37 @@ def test_antenna_transform_agrees_with_package():
         np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-6)
 
 
+def _g9_tables():
+    """(tag, elevations, ranges, reference z) of tests/golden/g9_beam_z.npz -- the reference's own
+    ``products.compute_beam_height(r*cos(el), el, 0)`` (products.py:70-89) on the synthetic sweep tables."""
+    from radar_processor_amd import synthetic
+    meta, arr = load_golden("g9_beam_z")
+    for tag, t in meta["tables"].items():
+        elev, _, rng_m = synthetic.sweep_geometry(t["n_elev"], 4, t["n_gates"])
+        assert [float(e) for e in elev] == t["elevations"] and float(rng_m[0]) == t["first_range"]
+        assert float(rng_m[1] - rng_m[0]) == t["range_step"], "sweep tables drifted from the ones the fixture was made with"
+        yield tag, np.asarray(elev, dtype=np.float64), np.asarray(rng_m, dtype=np.float64), arr[f"z_{tag}"]
+
+
+def test_gate_height_is_pinned_by_the_reference_beam_height():
+    """a1: the z coordinate of the gate transform against a REFERENCE-held formula.  The reference's x/y/z come from
+    PyART (absent: x and y stay parity-unpinned), but its ``compute_beam_height`` evaluates the same 4/3-earth height
+    with the same constants; g9 stores its float64 output for every sweep elevation and the range tables of configs 1,
+    2 and 4.  The oracle's and the package's float64 z agree with it to 2e-9 m (the reference goes through
+    ``r*cos/cos``), hence to the same float32 except for rare 1-ulp double roundings."""
+    from radar_processor_amd import synthetic
+    for tag, elev, rng_m, z_ref in _g9_tables():
+        for fn in (oracle.antenna_to_cartesian, synthetic.antenna_to_cartesian):
+            z = fn(rng_m[None, :], np.zeros((1, 1)), elev[:, None])[2]
+            assert z.shape == z_ref.shape
+            np.testing.assert_allclose(z, z_ref, rtol=0, atol=2e-9)
+            ulp = np.abs(z.astype(np.float32).view(np.int32).astype(np.int64)
+                         - z_ref.astype(np.float32).view(np.int32).astype(np.int64))
+            assert ulp.max() <= 1, tag
+        np.testing.assert_allclose(oracle.beam_height(rng_m[None, :] * np.cos(np.radians(elev))[:, None], elev[:, None]),
+                                   z_ref, rtol=0, atol=0)       # the oracle's restatement of products.py:70-89 itself
+
+
 # ------------------------------------------------------------------------------------------------
 # constant-elevation PPI + beam-height helpers (SURVEY.md §8(f) rank 2)
 # ------------------------------------------------------------------------------------------------

@@ -53,6 +53,77 @@ __global__ __launch_bounds__(256) void read_two_streams(const int* __restrict__ 
   if (acc == 123.456f) out[0] = acc;
 }
 
+// (3) blocked: workgroup b reads the contiguous block [b * block16, (b + 1) * block16) front to back, 4 KiB per step and
+// four steps in flight -- the access FRONT of the row-wise kernel (every resident workgroup sits in its own stretch of
+// the array) without any of its arithmetic.  block16 = 256 (4 KiB) is the grid-stride pattern again.
+__global__ __launch_bounds__(256) void read_blocked(const float4* __restrict__ a, long n16, long block16,
+                                                    float* __restrict__ out) {
+  const long beg = (long)blockIdx.x * block16;
+  const long end = beg + block16 < n16 ? beg + block16 : n16;
+  float acc = 0.0f;
+  long i = beg + threadIdx.x;
+  for (; i + 3 * 256 < end; i += 4 * 256) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = a[i + u * 256];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc += v[u].x + v[u].y + v[u].z + v[u].w;
+  }
+  for (; i < end; i += 256) { const float4 v = a[i]; acc += v.x + v.y + v.z + v.w; }
+  if (acc == 123.456f) out[0] = acc;
+}
+
+// (4) blocked read + a small write per workgroup: after reading its block, every `every`-th workgroup writes
+// `wbytes * every` bytes (dense: at wr + group * wbytes * every) -- the row-wise kernel's 1 KiB of grid per 68 KiB of
+// records, with the writes batched `every` workgroups at a time.  mode 1: the four 256-byte pieces of a workgroup go to
+// four lines 8000 bytes apart (the bench grid's layout) instead of one dense KiB.
+__global__ __launch_bounds__(256) void read_blocked_write(const float4* __restrict__ a, long n16, long block16,
+                                                          float* __restrict__ wr, int wfloats, int every, int mode) {
+  const long beg = (long)blockIdx.x * block16;
+  const long end = beg + block16 < n16 ? beg + block16 : n16;
+  float acc = 0.0f;
+  long i = beg + threadIdx.x;
+  for (; i + 3 * 256 < end; i += 4 * 256) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = a[i + u * 256];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc += v[u].x + v[u].y + v[u].z + v[u].w;
+  }
+  for (; i < end; i += 256) { const float4 v = a[i]; acc += v.x + v.y + v.z + v.w; }
+  if (blockIdx.x % every == 0) {
+    const long base = (long)(blockIdx.x / every) * wfloats * every;
+    if (mode == 0) {
+      for (int k = threadIdx.x; k < wfloats * every; k += 256) wr[base + k] = acc;
+    } else if (mode >= 2) {     // spread: workgroup b writes its piece into slab b % mode of `mode` equal slabs of the array
+      const long per_slab = ((long)gridDim.x + mode - 1) / mode;
+      const long piece = (long)(blockIdx.x % mode) * per_slab + blockIdx.x / mode;
+      for (int k = threadIdx.x; k < wfloats; k += 256) wr[piece * wfloats + k] = acc;
+    } else {            // 4 lines x 64 floats, lines 2000 floats apart, 32 workgroups per line group
+      const long grp = blockIdx.x / 32, col = blockIdx.x % 32;
+      const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+      wr[(grp * 4 + w) * 2000 + col * 62 + lane] = acc;
+    }
+  }
+}
+
+extern "C" int bw_read_blocked_write(const void* a, long bytes, long block_bytes, float* wr, int wbytes, int every, int mode,
+                                     void* stream) {
+  const long n16 = bytes / 16, block16 = block_bytes / 16;
+  const long blocks = (n16 + block16 - 1) / block16;
+  hipLaunchKernelGGL(read_blocked_write, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)a, n16,
+                     block16, wr, wbytes / 4, every, mode);
+  return (int)hipGetLastError();
+}
+
+extern "C" int bw_read_blocked(const void* a, long bytes, long block_bytes, float* out, void* stream) {
+  const long n16 = bytes / 16, block16 = block_bytes / 16;
+  const long blocks = (n16 + block16 - 1) / block16;
+  hipLaunchKernelGGL(read_blocked, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)a, n16, block16,
+                     out);
+  return (int)hipGetLastError();
+}
+
 extern "C" int bw_read_linear(const void* a, long bytes, int blocks, int unroll, float* out, void* stream) {
   const long n16 = bytes / 16;
   hipStream_t s = (hipStream_t)stream;
