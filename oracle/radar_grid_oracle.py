@@ -185,10 +185,12 @@ def csr_apply_f64(indptr, gate_indices, weights, field_values, field_mask, grid_
     return out.reshape(grid_shape)
 
 ROWWISE_TARGET = {1: 4, 2: 4, 3: 6, 4: 8}   # records per lane and row the row-wise kernel aims for, by field count
+ROWWISE_KPRE = {1: 3, 2: 3, 3: 2, 4: 3}     # records per lane and step (batch slots), by field count
+ROWWISE_CHAINS = 2                          # running sums per lane and value: batch slot k adds into chain k mod 2
 
 
 def csr_apply_rowwise_order(indptr, gate_indices, weights, fields, masks, grid_shape, fill_value=np.nan,
-                            lanes_hint: int = 0, fold: str = "f64") -> np.ndarray:
+                            lanes_hint: int = 0, kpre: int = 0, chains: int = ROWWISE_CHAINS) -> np.ndarray:
     """The masked weighted mean of :func:`csr_apply` (interpolate.py:69-104) with the float32 additions performed in
     exactly the order the row-wise kernel of ``rg_csr_compact_apply_packed_f32`` documents
     (radar_processor_amd/csrc/rg_csr_compact.hip), so that the kernel can be checked BIT FOR BIT on small cases:
@@ -197,8 +199,10 @@ def csr_apply_rowwise_order(indptr, gate_indices, weights, fields, masks, grid_s
       grouped in records of three;
     * per segment, L = 2^k lanes per row, k = ceil(log2(ceil(m / T))) capped at 6, m = span // (3 * rows) + 1 the mean
       records per row and T = ROWWISE_TARGET[fields] (``lanes_hint``: 1..64 = that many lanes, 70 + t = target t);
-    * lane j of a row sums the row's pairs of records q0 + j, q0 + j + L, ... (q0 = first pair // 3) in ascending order,
-      one running float32 (sum w*v, sum w) per field, a masked gate adding +0 to both;
+    * lane j of a row owns the row's records q0 + j, q0 + j + L, ... (q0 = first pair // 3); its t-th record sits in
+      batch slot t mod K, K = ROWWISE_KPRE[fields] (``kpre``: another K), and belongs to chain (t mod K) mod C, C =
+      ``chains`` = 2; per chain one running float32 (sum w*v, sum w) per field over the chain's pairs in ascending order, a
+      masked gate adding +0 to both; the lane's chains are then added in ascending order;
     * the L lane sums are folded by an xor butterfly (x[i] += x[i ^ 1], then ^ 2, ^ 4, ...);
     * value = float32(float64(sum w*v) / float64(sum w)) where sum w > 0, else ``fill_value``.
 
@@ -209,6 +213,8 @@ def csr_apply_rowwise_order(indptr, gate_indices, weights, fields, masks, grid_s
     w_all = np.asarray(weights, dtype=np.float32)
     nz, ny, nx = (int(v) for v in grid_shape)
     nf = len(fields)
+    kpre = int(kpre) if kpre else ROWWISE_KPRE[nf]
+    chains = max(1, min(int(chains), kpre))
     vals = [np.asarray(f, dtype=np.float32) for f in fields]
     excl = [np.zeros(vals[0].shape, dtype=bool) if m is None else np.asarray(m, dtype=bool) for m in masks]
     out = np.full((nf, nz * ny * nx), fill_value, dtype=np.float32)
@@ -239,27 +245,34 @@ def csr_apply_rowwise_order(indptr, gate_indices, weights, fields, masks, grid_s
                 rs = ps - seg_b
                 o = np.arange(rs, pe - seg_b)                     # pair offsets in the segment
                 q = o // 3 - rs // 3                              # record number within the row
-                lane, slot = q % lanes, (q // lanes) * 3 + o % 3
-                width = int(slot.max()) + 1
+                lane, trip = q % lanes, q // lanes
+                chain = (trip % kpre) % chains
+                # position of the pair inside its chain: the chain's records in ascending order, three pairs each
+                per_step = [len([k for k in range(kpre) if k % chains == c]) for c in range(chains)]      # slots per chain
+                before = [[len([k for k in range(s_) if k % chains == c]) for s_ in range(kpre)] for c in range(chains)]
+                rec_in_chain = (trip // kpre) * np.asarray(per_step)[chain] + np.asarray(before)[chain, trip % kpre]
+                col = rec_in_chain * 3 + o % 3
+                width = int(col.max()) + 1
                 g = gate_indices[ps:pe]
                 w = w_all[ps:pe]
                 for f in range(nf):
                     good = ~excl[f][g]
                     prod = np.where(good, w * vals[f][g], zero).astype(np.float32)   # float32 product, then the add
                     wgt = np.where(good, w, zero).astype(np.float32)
-                    mp = np.zeros((lanes, width), dtype=np.float32)
-                    mw = np.zeros((lanes, width), dtype=np.float32)
-                    mp[lane, slot] = prod
-                    mw[lane, slot] = wgt
+                    mp = np.zeros((chains, lanes, width), dtype=np.float32)
+                    mw = np.zeros((chains, lanes, width), dtype=np.float32)
+                    mp[chain, lane, col] = prod
+                    mw[chain, lane, col] = wgt
                     with np.errstate(invalid="ignore", over="ignore"):
-                        sp = np.add.accumulate(mp, axis=1, dtype=np.float32)[:, -1]    # strictly sequential per lane
-                        sw = np.add.accumulate(mw, axis=1, dtype=np.float32)[:, -1]
-                        fdt = np.float64 if fold == "f64" else np.float32
-                        sp, sw = sp.astype(fdt), sw.astype(fdt)
+                        chain_p = np.add.accumulate(mp, axis=2, dtype=np.float32)[:, :, -1]   # strictly sequential per chain
+                        chain_w = np.add.accumulate(mw, axis=2, dtype=np.float32)[:, :, -1]
+                        sp, sw = chain_p[0], chain_w[0]
+                        for c in range(1, chains):                                            # chains in ascending order
+                            sp, sw = (sp + chain_p[c]).astype(np.float32), (sw + chain_w[c]).astype(np.float32)
                         m = 1
                         while m < lanes:
                             partner = np.arange(lanes) ^ m
-                            sp, sw = (sp + sp[partner]).astype(fdt), (sw + sw[partner]).astype(fdt)
+                            sp, sw = (sp + sp[partner]).astype(np.float32), (sw + sw[partner]).astype(np.float32)
                             m <<= 1
                         if sw[0] > 0:
                             out[f, r] = np.float32(np.float64(sp[0]) / np.float64(sw[0]))

@@ -12,7 +12,8 @@ import threading
 from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_int64, c_uint8, c_void_p)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libradargrid_hip.so")
+# RG_LIBRARY: measurement-only override (A/B builds of the same sources with another -D, tools/gpu_r03_ab_slots.sh)
+LIB_PATH = os.environ.get("RG_LIBRARY") or os.path.join(HERE, "csrc", "libradargrid_hip.so")
 
 RG_MAX_FIELDS = 8
 RG_EXCLUDED_BITS = 0x7FD1CE5D

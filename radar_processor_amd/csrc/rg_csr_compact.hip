@@ -593,8 +593,10 @@ extern "C" int rg_csr_compact_pack(const void* indptr, int32_t indptr_is_i64, co
 // A STEP is one batch of KPRE record loads per lane; the loads of the next step (of the same rows, or of the next
 // 64 / L rows) are always requested before the current step is summed -- two register stages, as in the tile kernel.
 // Summation order (fixed by the geometry and the field count alone, so results are reproducible run to run, on any
-// window size and on the per-pair path of an over-wide chunk): per lane, its records in ascending order and a record's
-// pairs in order, one running (sum w*v, sum w) per field; then the xor butterfly of rg_row_phase.hpp over the L lanes.
+// window size and on the per-pair path of an over-wide chunk): a lane's t-th record of a row (t = 0, 1, ...) sits in
+// batch slot t mod KPRE and belongs to chain (t mod KPRE) mod 2; per lane and chain, the chain's records in ascending
+// order and a record's pairs in order, one running (sum w*v, sum w) per field; chain 0 + chain 1; then the xor butterfly
+// of rg_row_phase.hpp over the L lanes.
 // L is chosen per segment from its mean row length (kTarget records per lane and row).  This is NOT the order of
 // rg_csr_apply_f32: the two agree to float32 rounding, not bit for bit (the tile kernel over the same records, tile =
 // 384, does).
@@ -619,8 +621,13 @@ template <> struct RowwiseConfig<4> { static constexpr int kpre = 3, target = 8;
 // DIAG (timing-only diagnostics of tools/exp_placement4.py, results wrong by construction; one field only): bit 0 = the
 // window is not gathered (no dictionary / field reads), bit 1 = no output store, bit 2 / bit 3 = cache policy sc0 / nt on
 // the record loads, bit 4 = no record loads at all (the stream is replaced by a constant)
+#ifdef RG_ROWWISE_MIN_BLOCKS           // A/B builds only: cap the registers at what the single-chain kernel's occupancy needs
+#define RG_ROWWISE_BOUNDS __launch_bounds__(64 * kH, (NF == 1 ? 6 : NF <= 3 ? 5 : 4))
+#else
+#define RG_ROWWISE_BOUNDS __launch_bounds__(64 * kH)
+#endif
 template <typename IndT, int NF, int STRIDE, int DIAG = 0>
-__global__ __launch_bounds__(64 * kH) void csr_compact_rowwise_kernel(
+__global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
     const IndT* __restrict__ indptr, const int64_t* __restrict__ dict_ptr, const int32_t* __restrict__ dict, ChunkGrid cg,
     const float* __restrict__ packed, unsigned last_gate, float fill, int window_cap, long n_vox, float* __restrict__ out,
     const rg_u32x4* __restrict__ rec, const int64_t* __restrict__ rec_ptr, unsigned w_base, int lanes_hint,
@@ -795,9 +802,23 @@ __global__ __launch_bounds__(64 * kH) void csr_compact_rowwise_kernel(
   };
   auto run = [&](auto wtag) {
     constexpr bool kWindowed = decltype(wtag)::value;
-    float ap[NF], aw[NF];                           // the running sums of the lane's row, across the round's steps
+    // The running sums of the lane's row, across the round's steps: TWO chains -- batch slot k of every step adds into
+    // chain k mod 2's (sum w*v, sum w) --, added up when the round ends.  Two independent chains half as long as round 2's
+    // single one: worst relative error against the reference's ZDR fixtures 8.7e-6 -> 6.5e-6 at no cost (bench grid
+    // 8.051 vs 8.050 ms, same process and arrays; <= 1.3 % for 2-4 fields).  One chain per slot (three) reaches 4.3e-6 --
+    // exact sums would give 4.2e-6, the reference's own rounding -- but costs a wavefront of occupancy (75 -> 89 VGPRs for
+    // one field): +2.1 % on the bench grid, +10 / +21 % for two / four fields (profiles/r03_slots_ab.json).
+#ifdef RG_ROWWISE_SLOTS                 // A/B builds only (tools/gpu_r03_ab_slots.sh): 1 = round 2's one chain per lane
+    constexpr int KS = RG_ROWWISE_SLOTS < KPRE ? RG_ROWWISE_SLOTS : KPRE;
+#else
+    constexpr int KS = 2;
+#endif
+    float ap[KS][NF], aw[KS][NF];
 #pragma unroll
-    for (int f = 0; f < NF; ++f) ap[f] = aw[f] = 0.0f;
+    for (int k = 0; k < KS; ++k) {
+#pragma unroll
+      for (int f = 0; f < NF; ++f) ap[k][f] = aw[k][f] = 0.0f;
+    }
     auto consume = [&](const Step& r, const rg_u32x4& q4, int k) {     // k: slot of the step's batch (compile-time)
       // the record's pairs i = 0, 1, 2 belong to the lane's row iff lo <= i < lo + len (len = 0 for a lane without record)
       const int lo = r.lo0 - 3 * (k << lgl);
@@ -824,8 +845,8 @@ __global__ __launch_bounds__(64 * kH) void csr_compact_rowwise_kernel(
             v[0] = window[e * 3]; v[1] = window[e * 3 + 1]; v[2] = window[e * 3 + 2];
           } else if constexpr (kPremask) {
             const f32x2 term = (f32x2){w[i], w[i]} * reinterpret_cast<const f32x2*>(window)[e];
-            ap[0] += term.x;
-            aw[0] += term.y;
+            ap[k % KS][0] += term.x;
+            aw[k % KS][0] += term.y;
             continue;
           } else if constexpr (STRIDE == 1) {
             v[0] = window[e];
@@ -847,8 +868,8 @@ __global__ __launch_bounds__(64 * kH) void csr_compact_rowwise_kernel(
 #pragma unroll
         for (int f = 0; f < NF; ++f) {   // masked gate: contributes to neither sum (interpolate.py:78-79)
           const bool good = rg::f32_bits(v[f]) != RG_EXCLUDED_BITS;
-          ap[f] += good ? w[i] * v[f] : 0.0f;
-          aw[f] += good ? w[i] : 0.0f;
+          ap[k % KS][f] += good ? w[i] * v[f] : 0.0f;
+          aw[k % KS][f] += good ? w[i] : 0.0f;
         }
       }
     };
@@ -862,9 +883,16 @@ __global__ __launch_bounds__(64 * kH) void csr_compact_rowwise_kernel(
       float sv[2 * NF];
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
-        sv[2 * f] = ap[f];
-        sv[2 * f + 1] = aw[f];
-        ap[f] = aw[f] = 0.0f;
+        float sp = ap[0][f], sw = aw[0][f];           // chains in ascending order
+        ap[0][f] = aw[0][f] = 0.0f;
+#pragma unroll
+        for (int k = 1; k < KS; ++k) {
+          sp += ap[k][f];
+          sw += aw[k][f];
+          ap[k][f] = aw[k][f] = 0.0f;
+        }
+        sv[2 * f] = sp;
+        sv[2 * f + 1] = sw;
       }
       rg::butterfly<2 * NF>(sv, nl);
       if constexpr (kRegs) {      // every lane of a row holds the row's sums: lane == row fetches them

@@ -277,6 +277,69 @@ def test_c2_compact_csr_is_bit_identical(c2):
         assert bool(torch.equal(again.view(torch.int32), got_r.view(torch.int32)))
 
 
+def test_c3_fused_pass_against_oracle_rows_with_the_error_tail(c2):
+    """Config 3 as bench.py runs it -- DBZH + ZDR + RHOHV, the RHOHV >= 0.8 QC mask OR-ed into every field's own mask, ONE
+    fused three-field row-wise pass -- against ``oracle.csr_apply`` (interpolate.py:69-104 with the merged masks of
+    :59-64) on 60 whole (z,y) rows of the full config-2 grid, per field.  Beyond the pass/fail bar (same voxels filled,
+    rtol 1e-5 + 1e-5 * max|field|) it MEASURES the tail the bar hides: the worst purely relative error where |want| >
+    1e-3 * max|field| (asserted <= 1e-5 with no absolute term) and how many voxels pass only thanks to the floor --
+    written to gpurun_out/parity_relerr_fullsize.json next to the fixture-level parity_relerr.json."""
+    import json
+    import os
+    rg, torch, geom, dev, vol = c2["rg"], c2["torch"], c2["geom"], c2["dev"], c2["vol"]
+    from radar_processor_amd.gridding import CsrGridder
+    names = ["DBZH", "ZDR", "RHOHV"]
+    f = [c2["fields"][n] for n in names]
+    m = [c2["masks"][n] for n in names]
+    qc = rg.device_gate_mask(c2["fields"]["RHOHV"], "below", 0.8)
+    gr = CsrGridder(geom, f[0].numel(), 3, device=dev, compact=True)
+    assert gr.compact is not None and gr.packed_stream and gr.tile == 0          # the fused row-wise pass
+    gr.pack(f, m, qc)
+    grid = torch.empty((3, gr.n_vox), dtype=torch.float32, device=dev)
+    gr.apply(grid)
+    nz, ny, nx = c2["cfg"]["grid_shape"]
+    grid = grid.view(3, nz, ny, nx)
+    csr = geom.device_csr(dev)
+    qc_host = qc.cpu().numpy().astype(bool)
+    rng = np.random.default_rng(33)
+    rows = {(0, 500), (3, 499), (7, 501), (12, 500), (19, 499), (0, 0), (19, 999)}          # radar column, corners
+    while len(rows) < 60:
+        rows.add((int(rng.integers(0, nz)), int(rng.integers(0, ny))))
+    report = {}
+    for k, name in enumerate(names):
+        data, own = oracle.merge_masks(vol.fields[name])
+        mask = own | qc_host                                                     # interpolate.py:59-64
+        scale = float(np.abs(data[np.isfinite(data) & ~mask]).max())
+        rec = dict(rows=len(rows), voxels=0, significant=0, needed_floor=0, max_rel_significant=0.0, max_abs_over_scale=0.0)
+        for iz, iy in sorted(rows):
+            v0 = (iz * ny + iy) * nx
+            ip = csr.indptr[v0:v0 + nx + 1].cpu().numpy().astype(np.int64)
+            idx = csr.gate_indices[int(ip[0]):int(ip[-1])].cpu().numpy()
+            w = csr.weights[int(ip[0]):int(ip[-1])].cpu().numpy()
+            want = oracle.csr_apply(ip - ip[0], idx, w, data, mask, (1, 1, nx))[0, 0]
+            got = grid[k, iz, iy].cpu().numpy()
+            np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+            np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5 * scale, equal_nan=True)
+            filled = np.isfinite(want)
+            err = np.abs(got[filled].astype(np.float64) - want[filled].astype(np.float64))
+            mag = np.abs(want[filled].astype(np.float64))
+            sig = mag > 1e-3 * scale
+            rec["voxels"] += int(filled.sum())
+            rec["significant"] += int(sig.sum())
+            rec["needed_floor"] += int((err > 1e-5 * mag).sum())
+            if sig.any():
+                rec["max_rel_significant"] = max(rec["max_rel_significant"], float((err[sig] / mag[sig]).max()))
+            if err.size:
+                rec["max_abs_over_scale"] = max(rec["max_abs_over_scale"], float(err.max() / scale))
+        assert rec["voxels"] > 20_000 and rec["max_rel_significant"] <= 1e-5, (name, rec)
+        report[name] = rec
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "parity_relerr_fullsize.json"), "w") as fh:
+        json.dump({"config": "C3: fused DBZH+ZDR+RHOHV row-wise pass, RHOHV>=0.8 mask, 60 whole rows of 20x1000x1000 vs "
+                             "oracle.csr_apply", "per_field": report}, fh, indent=1)
+    print("parity_relerr_fullsize", json.dumps(report))
+
+
 def test_c2_passes_use_the_compact_copy_from_the_first(c2):
     """gridding._use_compact: a geometry of config 2's size grids through the compact copy from its first pass on --
     single- or multi-field, row-wise kernel over the packed records -- so every pass of the geometry returns the same bits;

@@ -1,0 +1,169 @@
+"""BASELINE config 4 at its full size THROUGH THE PATH ``bench.py --config C4`` TIMES: 14x720x2000 gates ->
+40x2000x2000, 33 G pairs, ``layout="auto"`` -> the packed-only geometry (row pointers + dictionaries + 16-byte records,
+180 GB, built one slab of levels at a time) gridded by the row-wise kernel.  The reference cannot represent this
+geometry (int32 ``indptr``), so parity is: the CSR-free K2 gridder on every voxel, the oracle's
+brute-force builder (compute.py:46-91) on windows in the first slab, the last slab, across a slab seam and inside the
+SPLIT chunk around the radar, and ``oracle.csr_apply`` (interpolate.py:69-104) on whole (z,y) rows including the
+radar column.
+
+A separate module on purpose: it sorts after test_gpu_fullsize.py, whose module fixtures (135 GB of METRIC geometry)
+are torn down before this one allocates."""
+import numpy as np
+import pytest
+
+from oracle import radar_grid_oracle as oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def c4(tmp_path_factory):
+    import gc
+    import torch
+    import radar_processor_amd as rg
+    from radar_processor_amd import synthetic
+    rg.load_library()
+    gc.collect()
+    torch.cuda.empty_cache()
+    cfg = synthetic.CONFIGS["C4"]
+    vol = synthetic.make_volume(cfg["n_elev"], cfg["n_az"], cfg["n_gates"], seed=4, fields=("DBZH",))
+    dev = torch.device("cuda", 0)
+    geom = rg.compute_grid_geometry(vol.gate_x, vol.gate_y, vol.gate_z, cfg["grid_shape"], cfg["grid_limits"],
+                                    str(tmp_path_factory.mktemp("geom_c4")), layout="auto")
+    f = torch.from_numpy(np.ascontiguousarray(np.ma.getdata(vol.fields["DBZH"]))).to(dev)
+    m = torch.from_numpy(np.ma.getmaskarray(vol.fields["DBZH"]).astype(np.uint8)).to(dev)
+    ctx = dict(rg=rg, torch=torch, cfg=cfg, vol=vol, geom=geom, dev=dev, f=f, m=m)
+    yield ctx
+    ctx.clear()
+    del geom, f, m
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def _rowwise_grid(c4):
+    if "grid" not in c4:
+        c4["grid"] = c4["rg"].grid_fields_device(c4["geom"], [c4["f"]], [c4["m"]])[0]
+    return c4["grid"]
+
+
+def test_c4_auto_layout_is_packed_only_with_a_split_chunk(c4):
+    from radar_processor_amd import _native
+    from radar_processor_amd.grid_geometry import CompactCSR
+    torch, geom, dev, cfg = c4["torch"], c4["geom"], c4["dev"], c4["cfg"]
+    csr = geom.device_csr(dev)
+    compact = geom.device_compact(dev)
+    assert csr.gate_indices is None and csr.weights is None          # 'auto' kept the packed layout alone
+    assert compact.local_idx is None and compact.rec is not None and compact.rec_order == _native.RG_REC_ORDER_DISPATCH
+    assert csr.is_i64 and csr.n_vox == 160_000_000 and csr.n_pairs > 3.0e10
+    assert compact.rec.shape[0] * 16 < 5.45 * csr.n_pairs and geom.memory_usage_mb() < 200e3
+    ip = csr.indptr
+    assert int(ip[0]) == 0 and int(ip[-1]) == csr.n_pairs and int((ip[1:] - ip[:-1]).min()) >= 0
+    # the patch around the radar holds more than 65536 distinct gates: stored split, one dictionary per wavefront
+    sizes = compact.dict_ptr[1:] - compact.dict_ptr[:-1]
+    split = torch.nonzero(sizes > 65536).view(-1)
+    assert split.numel() >= 1
+    nz, ny, nx = cfg["grid_shape"]
+    nsx, nyg, n_chunks = CompactCSR.layout(cfg["grid_shape"])
+    c = int(split[0])
+    plane, rem = divmod(c, nyg * nsx)
+    yg, sx = divmod(rem, nsx)
+    assert abs(yg * _native.RG_COMPACT_LINES - ny // 2) <= 8 and abs(sx - nsx // 2) <= 1        # it IS the radar's patch
+    c4["split_chunk"] = (plane, yg, sx)
+    header = compact.dict[int(compact.dict_ptr[c]):int(compact.dict_ptr[c]) + _native.RG_COMPACT_LINES].cpu().numpy()
+    assert header[0] == _native.RG_COMPACT_LINES and (np.diff(header) > 0).all() and header[-1] < int(sizes[c])
+    # rec_ptr: one slot per (block, wavefront), monotone, ceil(pairs / 3) records per segment overall
+    rp = compact.rec_ptr
+    assert rp.numel() == n_chunks * _native.RG_COMPACT_LINES + 1 and int(rp[-1]) == compact.rec.shape[0]
+    assert int((rp[1:] - rp[:-1]).min()) >= 0
+
+
+def test_c4_rowwise_grid_equals_csr_free_gridder_on_every_voxel(c4):
+    """compute.py:46-91 + interpolate.py:69-104 two independent ways: the packed-only geometry through the row-wise
+    kernel (the path bench.py --config C4 times) and K2, which never materialises a CSR."""
+    rg, torch, dev, vol, cfg = c4["rg"], c4["torch"], c4["dev"], c4["vol"], c4["cfg"]
+    grid = _rowwise_grid(c4)
+    search = rg.RoiSearch(vol.gate_x, vol.gate_y, vol.gate_z, cfg["grid_shape"], cfg["grid_limits"])
+    k2 = rg.roi_grid_fields_device(search, [c4["f"]], [c4["m"]])[0]
+    del search
+    assert bool(torch.equal(torch.isnan(grid), torch.isnan(k2)))
+    f = c4["f"]
+    scale = float(f[torch.isfinite(f) & (c4["m"] == 0)].abs().max())
+    worst = float(torch.nan_to_num(grid - k2, nan=0.0).abs().max())
+    assert worst <= 1e-5 * scale, worst
+    assert 0.6 < float(torch.isfinite(grid).float().mean()) < 0.9
+    again = rg.grid_fields_device(c4["geom"], [c4["f"]], [c4["m"]])[0]         # a fixed order: the same bits run to run
+    assert bool(torch.equal(again.view(torch.int32), grid.view(torch.int32)))
+    del k2, again
+
+
+def test_c4_decode_against_the_brute_force_builder(c4):
+    """``CompactCSR.decode`` / ``decode_weights`` of the slab-built packed-only geometry against ``oracle.build_geometry``
+    (the restatement of compute.py:46-91) on 4-voxel windows: in the first slab, in the last one, on both sides of a slab
+    seam, inside the split chunk, and far out where the rows are longest."""
+    torch, geom, dev, vol, cfg = c4["torch"], c4["geom"], c4["dev"], c4["vol"], c4["cfg"]
+    csr, compact = geom.device_csr(dev), geom.device_compact(dev)
+    nz, ny, nx = cfg["grid_shape"]
+    limits = cfg["grid_limits"]
+    xc = np.linspace(limits[2][0], limits[2][1], nx, dtype="float32")
+    yc = np.linspace(limits[1][0], limits[1][1], ny, dtype="float32")
+    zc = np.linspace(limits[0][0], limits[0][1], nz, dtype="float32")
+    plane, yg, sx = c4.get("split_chunk", (0, ny // 8, nx // 128))
+    level_pairs = csr.indptr[::ny * nx].cpu().numpy()
+    # slabs of the builder: whole levels up to 1.2e9 pairs each (geometry_builder._build_compact_only)
+    seam = next(z for z in range(1, nz) if level_pairs[z + 1] - level_pairs[z - 1] > 1_200_000_000)
+    windows = [(0, 3, 17), (0, ny // 2, nx // 2 - 2), (nz - 1, ny - 5, nx - 40), (seam - 1, ny - 1, 1200), (seam, 0, 1200),
+               (plane, yg * 4 + 1, sx * (nx // ((nx + 63) // 64)) + 20), (20, 1000, 1960), (8, 1710, 290)]
+    checked = 0
+    for iz, iy, ix0 in windows:
+        v0 = (iz * ny + iy) * nx + ix0
+        ip = csr.indptr[v0:v0 + 5].cpu().numpy()
+        idx = compact.decode(csr, v0, v0 + 4).cpu().numpy()
+        w = compact.decode_weights(csr, v0, v0 + 4).cpu().numpy()
+        assert idx.shape[0] == w.shape[0] == ip[4] - ip[0]
+        sub = ((float(zc[iz]), float(zc[iz])), (float(yc[iy]), float(yc[iy])), (float(xc[ix0]), float(xc[ix0 + 3])))
+        o_ip, o_idx, o_w = oracle.build_geometry(vol.gate_x, vol.gate_y, vol.gate_z, (1, 1, 4), sub)
+        for k in (0, 3):       # the end points of a 4-point linspace are the grid's own float32 coordinates
+            lo, hi = int(ip[k] - ip[0]), int(ip[k + 1] - ip[0])
+            order = np.argsort(idx[lo:hi], kind="stable")
+            np.testing.assert_array_equal(idx[lo:hi][order], o_idx[o_ip[k]:o_ip[k + 1]])
+            ulp = np.abs(w[lo:hi][order].view(np.int32).astype(np.int64)
+                         - o_w[o_ip[k]:o_ip[k + 1]].view(np.int32).astype(np.int64))
+            assert ulp.max(initial=0) <= 1
+            checked += hi - lo
+    assert checked > 1000
+    # a row range across the slab seam (last line of one level, first line of the next) decodes consistently in one call
+    r0 = (seam * ny - 1) * nx
+    both = compact.decode(csr, r0, r0 + 2 * nx)
+    assert torch.equal(both, torch.cat([compact.decode(csr, r0, r0 + nx), compact.decode(csr, r0 + nx, r0 + 2 * nx)]))
+    assert both.numel() == int(csr.indptr[r0 + 2 * nx] - csr.indptr[r0])
+    assert int(both.min()) >= 0 and int(both.max()) <= csr.max_gate
+
+
+def test_c4_oracle_rows_including_the_radar_column(c4):
+    """``oracle.csr_apply`` (interpolate.py:69-104) on whole (z,y) rows of the row-wise grid, their CSR rows decoded from
+    the packed records: the row through the radar at the level of the split chunk, its neighbours, a row in the last slab,
+    both rows of a slab seam and an edge row."""
+    torch, geom, dev, vol, cfg = c4["torch"], c4["geom"], c4["dev"], c4["vol"], c4["cfg"]
+    csr, compact = geom.device_csr(dev), geom.device_compact(dev)
+    grid = _rowwise_grid(c4)
+    nz, ny, nx = cfg["grid_shape"]
+    data, mask = oracle.merge_masks(vol.fields["DBZH"])
+    scale = float(np.abs(data[np.isfinite(data) & ~mask]).max())
+    plane = c4.get("split_chunk", (0, 0, 0))[0]
+    level_pairs = csr.indptr[::ny * nx].cpu().numpy()
+    seam = next(z for z in range(1, nz) if level_pairs[z + 1] - level_pairs[z - 1] > 1_200_000_000)
+    rows = [(plane, ny // 2), (plane, ny // 2 - 1), (plane + 1, ny // 2 + 2), (nz - 1, 700), (seam - 1, ny - 1), (seam, 0),
+            (5, 3)]
+    pairs = 0
+    for iz, iy in rows:
+        v0 = (iz * ny + iy) * nx
+        ip = csr.indptr[v0:v0 + nx + 1].cpu().numpy()
+        idx = compact.decode(csr, v0, v0 + nx).cpu().numpy()
+        w = compact.decode_weights(csr, v0, v0 + nx).cpu().numpy()
+        want = oracle.csr_apply(ip - ip[0], idx, w, data, mask, (1, 1, nx))[0, 0]
+        got = grid[iz, iy].cpu().numpy()
+        np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5 * scale, equal_nan=True)
+        pairs += int(ip[-1] - ip[0])
+    assert np.isfinite(grid[plane, ny // 2, nx // 2].item())          # the radar's own column is filled
+    assert pairs > 500_000

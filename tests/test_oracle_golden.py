@@ -179,7 +179,7 @@ def test_rowwise_order_restatement_is_the_reference_mean(name):
         np.testing.assert_allclose(fused[k], want, rtol=1e-5, atol=atol, equal_nan=True)
         hint = 70 + oracle.ROWWISE_TARGET[len(data)]          # a single-field pass with the fused pass's lane split
         single = oracle.csr_apply_rowwise_order(ref["indptr"], idx, ref["weights"], data[k:k + 1], masks[k:k + 1], shape,
-                                                lanes_hint=hint)[0]
+                                                lanes_hint=hint, kpre=oracle.ROWWISE_KPRE[len(data)])[0]   # and batch
         np.testing.assert_array_equal(single, fused[k])
         for lanes in (1, 64):
             other = oracle.csr_apply_rowwise_order(ref["indptr"], idx, ref["weights"], data[k:k + 1], masks[k:k + 1],

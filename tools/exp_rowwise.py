@@ -26,12 +26,25 @@ def main():
     ap.add_argument("--fields", default="3")
     ap.add_argument("--codes", default="0,2004,2008,2016,2074,2076,2078")
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--libs", default="", help="name=path,... : other builds of the library to time next to the in-tree one, "
+                                                "same process, same arrays (every code is run through every library)")
     args = ap.parse_args()
     import torch
     import radar_processor_amd as rg
     from radar_processor_amd import synthetic
     from radar_processor_amd.gridding import CsrGridder
     rg.load_library()
+    libs = []
+    if args.libs:
+        import ctypes
+        from radar_processor_amd import _native
+        for item in args.libs.split(","):
+            name, path = item.split("=")
+            lib = ctypes.CDLL(os.path.abspath(path))
+            for sym, (restype, argtypes) in _native.SIGNATURES.items():
+                fn = getattr(lib, sym)
+                fn.restype, fn.argtypes = restype, argtypes
+            libs.append((name, lib))
     dev = torch.device("cuda", 0)
     cfg = synthetic.CONFIGS[args.config]
     names = ("DBZH", "ZDR", "RHOHV")
@@ -68,6 +81,10 @@ def main():
             g.window = compact.window_for(nf)
             g.packed = ref.packed
             variants.append((f"row{code}", g, torch.empty_like(out_ref)))
+            for lname, lib in libs:
+                g2 = CsrGridder(geom, fl[0].numel(), nf, device=dev, compact=True, tile=code)
+                g2.compact, g2.packed_stream, g2.window, g2.packed, g2.lib = compact, True, g.window, ref.packed, lib
+                variants.append((f"row{code}@{lname}", g2, torch.empty_like(out_ref)))
         times = {v[0]: [] for v in variants}
         rng = np.random.default_rng(7)
         for r in range(args.rounds + 1):

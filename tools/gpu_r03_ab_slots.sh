@@ -1,0 +1,29 @@
+#!/bin/bash
+# Round 3 A/B, one process per configuration, same arrays: the row-wise kernel as shipped against builds of the same
+# sources with another number of running sums per lane (-DRG_ROWWISE_SLOTS=1: round 2's single chain; =2) and with a
+# register cap (-DRG_ROWWISE_MIN_BLOCKS), loaded next to the in-tree library through tools/exp_rowwise.py --libs.
+set -u
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+TAG=${1:-r03b}
+python3 -m radar_processor_amd.build > gpurun_out/${TAG}_build.log 2>&1 || exit 1
+C=radar_processor_amd/csrc
+build_variant() {   # name, flags...
+  local name=$1; shift
+  hipcc -std=c++17 -O3 --offload-arch=gfx950 -fPIC -Iinclude -I$C -ffp-contract=off "$@" -c $C/rg_csr_compact.hip -o /tmp/${TAG}_$name.o &&
+  hipcc --offload-arch=gfx950 -shared -fPIC $C/rg_core.o $C/rg_csr_apply.o /tmp/${TAG}_$name.o $C/rg_products.o $C/rg_geometry.o $C/rg_roi_grid.o $C/rg_raster.o -o /tmp/${TAG}_lib$name.so
+}
+build_variant slots1 -DRG_ROWWISE_SLOTS=1 & build_variant slots2 -DRG_ROWWISE_SLOTS=2 & build_variant slots3cap -DRG_ROWWISE_SLOTS=3 -DRG_ROWWISE_MIN_BLOCKS & build_variant slots3 -DRG_ROWWISE_SLOTS=3 &
+wait
+LIBS="slots1=/tmp/${TAG}_libslots1.so,slots2=/tmp/${TAG}_libslots2.so,slots3=/tmp/${TAG}_libslots3.so,slots3cap=/tmp/${TAG}_libslots3cap.so"
+for cfg in C2 METRIC; do
+  timeout -k 10 400 python3 tools/exp_rowwise.py --config $cfg --fields 1,2,3,4 --codes 0 --rounds 15 --libs $LIBS > gpurun_out/${TAG}_slots_${cfg}.json 2> gpurun_out/${TAG}_slots_${cfg}.log || exit 1
+done
+python3 - "$TAG" <<'PY'
+import json, sys
+tag = sys.argv[1]
+for cfg in ("C2", "METRIC"):
+    d = json.load(open(f"gpurun_out/{tag}_slots_{cfg}.json"))
+    for nf in (1, 2, 3, 4):
+        print(cfg, f"F{nf}", {r["kernel"]: r["ms"] for r in d["runs"] if r["fields"] == nf})
+PY
