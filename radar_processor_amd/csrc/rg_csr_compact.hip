@@ -41,6 +41,10 @@ using rg_u32x4 = unsigned __attribute__((ext_vector_type(4)));
 __device__ rg_u32x4 rg_buffer_load_v4u32(__amdgpu_buffer_rsrc_t, int voffset, int soffset, int aux)
     __asm("llvm.amdgcn.raw.ptr.buffer.load.v4i32");
 
+// v_mul_legacy_f32 by intrinsic name (this clang has no __builtin_amdgcn_fmul_legacy): 0 * x = +0 for EVERY x, NaN and
+// infinity included; any other product is the IEEE one.
+__device__ float rg_fmul_legacy(float, float) __asm("llvm.amdgcn.fmul.legacy");
+
 namespace {
 
 using rg::f32x2;
@@ -837,10 +841,13 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         const bool mine = (unsigned)(i - lo) < len;
-        const int p = pos[i] < nd_last ? pos[i] : nd_last;
+        // windowed: no clamp -- a position is 16 bits by construction, and an LDS read beyond the workgroup's allocation
+        // returns zeros instead of faulting (a corrupt record cannot do worse than a wrong value)
+        const int p = kWindowed ? pos[i] : (pos[i] < nd_last ? pos[i] : nd_last);
         float v[STRIDE];
         if constexpr (kWindowed) {
           const int e = mine ? p : nd_all;          // not this row's pair: the all-EXCLUDED sentinel entry
+          __builtin_assume((unsigned)e <= 65536u);  // lets e * 12 be a 24-bit multiply-add instead of a 64-bit one
           if constexpr (kNarrow) {
             v[0] = window[e * 3]; v[1] = window[e * 3 + 1]; v[2] = window[e * 3 + 2];
           } else if constexpr (kPremask) {
@@ -868,8 +875,17 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
 #pragma unroll
         for (int f = 0; f < NF; ++f) {   // masked gate: contributes to neither sum (interpolate.py:78-79)
           const bool good = rg::f32_bits(v[f]) != RG_EXCLUDED_BITS;
+          // ONE select per field and pair: the effective weight is w or +0, and v_mul_legacy_f32 makes 0 * sentinel = +0
+          // where an IEEE multiply would make NaN (for a non-zero weight the two multiplies are the same operation, so
+          // unmasked NaN / Inf data propagates exactly as before: same bits as good ? w * v : 0)
+#ifdef RG_ROWWISE_TWO_SELECTS            // A/B builds only: round 2's form of the same arithmetic
           ap[k % KS][f] += good ? w[i] * v[f] : 0.0f;
           aw[k % KS][f] += good ? w[i] : 0.0f;
+#else
+          const float wf = good ? w[i] : 0.0f;
+          ap[k % KS][f] += rg_fmul_legacy(wf, v[f]);
+          aw[k % KS][f] += wf;
+#endif
         }
       }
     };

@@ -13,9 +13,15 @@ build_variant() {   # name, flags...
   hipcc -std=c++17 -O3 --offload-arch=gfx950 -fPIC -Iinclude -I$C -ffp-contract=off "$@" -c $C/rg_csr_compact.hip -o /tmp/${TAG}_$name.o &&
   hipcc --offload-arch=gfx950 -shared -fPIC $C/rg_core.o $C/rg_csr_apply.o /tmp/${TAG}_$name.o $C/rg_products.o $C/rg_geometry.o $C/rg_roi_grid.o $C/rg_raster.o -o /tmp/${TAG}_lib$name.so
 }
+if [ "${2:-slots}" = "selects" ]; then      # the one-select + v_mul_legacy_f32 form of the masked product against round 2's two selects
+  build_variant twoselects -DRG_ROWWISE_TWO_SELECTS &
+  wait
+  LIBS="twoselects=/tmp/${TAG}_libtwoselects.so"
+else
 build_variant slots1 -DRG_ROWWISE_SLOTS=1 & build_variant slots2 -DRG_ROWWISE_SLOTS=2 & build_variant slots3cap -DRG_ROWWISE_SLOTS=3 -DRG_ROWWISE_MIN_BLOCKS & build_variant slots3 -DRG_ROWWISE_SLOTS=3 &
 wait
 LIBS="slots1=/tmp/${TAG}_libslots1.so,slots2=/tmp/${TAG}_libslots2.so,slots3=/tmp/${TAG}_libslots3.so,slots3cap=/tmp/${TAG}_libslots3cap.so"
+fi
 for cfg in C2 METRIC; do
   timeout -k 10 400 python3 tools/exp_rowwise.py --config $cfg --fields 1,2,3,4 --codes 0 --rounds 15 --libs $LIBS > gpurun_out/${TAG}_slots_${cfg}.json 2> gpurun_out/${TAG}_slots_${cfg}.log || exit 1
 done
@@ -25,5 +31,10 @@ tag = sys.argv[1]
 for cfg in ("C2", "METRIC"):
     d = json.load(open(f"gpurun_out/{tag}_slots_{cfg}.json"))
     for nf in (1, 2, 3, 4):
-        print(cfg, f"F{nf}", {r["kernel"]: r["ms"] for r in d["runs"] if r["fields"] == nf})
+        print(cfg, f"F{nf}", {r["kernel"]: r["ms"] for r in d["runs"] if r["fields"] == nf},
+              "same bits as in-tree:", [r["same_bits_as_first_row_variant"] for r in d["runs"] if r["fields"] == nf and "@" in r["kernel"]])
 PY
+if [ "${3:-}" = "tests" ]; then
+  timeout -k 10 900 python3 -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_tests.log 2>&1
+  rc=$?; tail -4 gpurun_out/${TAG}_tests.log; exit $rc
+fi
