@@ -207,9 +207,13 @@ __global__ __launch_bounds__(256) void stream_read_kernel(const float4* __restri
 extern "C" int rg_stream_read_probe(const void* buffer, int64_t bytes, float* sink, rg_stream_t stream) {
   RG_REQUIRE(buffer && sink && bytes >= 16, RG_EINVAL, "rg_stream_read_probe: null buffer/sink or fewer than 16 bytes");
   RG_REQUIRE(rg::aligned16(buffer), RG_EALIGN, "rg_stream_read_probe: buffer must be 16-byte aligned");
-  const long n16 = bytes / 16, blocks = (n16 + 255) / 256;
-  RG_REQUIRE(blocks <= 0x7FFFFFFFL, RG_EUNSUPPORTED, "rg_stream_read_probe: more than 2^31 workgroups (8 TiB)");
-  hipLaunchKernelGGL(stream_read_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                     static_cast<const float4*>(buffer), n16, sink);
+  // a dispatch holds at most 2^32 - 1 work-items: buffers beyond 32 GiB take several launches back to back
+  const long n16 = bytes / 16;
+  const long kPerLaunch = 1L << 31;                      // 16-byte elements (= work-items) per launch
+  for (long first = 0; first < n16; first += kPerLaunch) {
+    const long n = n16 - first < kPerLaunch ? n16 - first : kPerLaunch;
+    hipLaunchKernelGGL(stream_read_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const float4*>(buffer) + first, n, sink);
+  }
   return rg::check_launch("rg_stream_read_probe");
 }

@@ -48,10 +48,11 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 
 
 // float32 weight from the float32 d2 (compute.py:82-87); relative error < 2e-6
+// inv_r2q: Barnes -- MINUS log2(e) * 4 / r2, so that exp(-d2 / (r2 / 4)) is one multiply and one v_exp_f32 (= 2^x)
 template <int W>
 __device__ __forceinline__ float weight_from_f32(float d2f, float r2f, float inv_r2q) {
   if constexpr (W == RG_W_BARNES2) {
-    return __expf(-(d2f * inv_r2q)) + 1e-5f;
+    return __builtin_amdgcn_exp2f(d2f * inv_r2q) + 1e-5f;
   } else if constexpr (W == RG_W_CRESSMAN) {
     return (r2f - d2f) / (r2f + d2f);
   } else {
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(rg::kBlock) void roi_block_kernel(SearchArgs a, con
     // float32 d2 carries < 4e-7 relative error: outside [r2_lo, r2_hi] the float32 comparison is already exact
     const float r2_hi = vlive ? (float)(r2 * (1.0 + 2e-6)) * (1.0f + 2.4e-7f) : -1.0f;
     const float r2_lo = vlive ? (float)(r2 * (1.0 - 2e-6)) * (1.0f - 2.4e-7f) : -1.0f;  // dead lanes never hit
-    const float inv_r2q = (float)(4.0 / r2);
+    const float inv_r2q = (float)(-1.4426950408889634 * 4.0 / r2);      // see weight_from_f32
     // ---- block-wide (wave-uniform) quantities ------------------------------------------------------------
     double rmax = vlive ? r : 0.0;
 #pragma unroll
