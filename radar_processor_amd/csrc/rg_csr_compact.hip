@@ -991,9 +991,7 @@ int launch_rowwise(int window_cap, const void* indptr, const int64_t* dict_ptr, 
   const long room = (65536 - kStatic - 256) / (4 * WS) - 1;
   if (window_cap > room) window_cap = (int)room;
   const long n_chunks = chunk_count(cg);
-  if (chunks_per_block <= 0) chunks_per_block = kRowwiseChunksPerBlock;
-  // never fewer workgroups than fill the chip a few times over: small grids keep one chunk per workgroup
-  while (chunks_per_block > 1 && n_chunks / chunks_per_block < 8192) chunks_per_block >>= 1;
+  if (chunks_per_block <= 0) chunks_per_block = kRowwiseChunksPerBlock;      // an explicit request (tile = 2200 + n) is honoured
   hipLaunchKernelGGL((csr_compact_rowwise_kernel<IndT, NF, STRIDE, DIAG>),
                      dim3((unsigned)((n_chunks + chunks_per_block - 1) / chunks_per_block)), dim3(64 * kH),
                      ((size_t)(window_cap + 1) * WS * sizeof(float) + 15) / 16 * 16, s, static_cast<const IndT*>(indptr),

@@ -501,6 +501,35 @@ def test_compact_and_packed_kernels_fuzz(rg, seed):
             live = ~np.isnan(emu)
             assert np.array_equal(got_np.view(np.int32)[live], emu.view(np.int32)[live]), ("row-wise order", nf, hint, shape)
         g_r.tile = 0
+        # several consecutive chunks per workgroup (tile = 2200 + n; the window is refilled behind a barrier): the same bits
+        for cpw in (2, 5):
+            g_r.tile = 2200 + cpw
+            got.fill_(9.0)
+            g_r.apply(got, fill_value=-3.0)
+            assert torch.equal(got.view(torch.int32), row.view(torch.int32)), ("chunks per workgroup", cpw, nf, shape)
+        g_r.tile = 0
+        rows_by_order = row
+        # the OTHER record order (line-major segments instead of dispatch order): other slots, the same records, the same bits
+        # from both kernels, and the same positions and weights decoded
+        if nf in (1, 3):
+            from radar_processor_amd import _native, grid_geometry
+            other = CompactCSR(compact.local_idx, compact.dict_ptr, compact.dict, compact.max_dict, compact.window_cap,
+                               compact.grid_shape, compact.chunk_pairs, compact.chunk_counts)
+            assert compact.rec_order == grid_geometry.DEFAULT_REC_ORDER == _native.RG_REC_ORDER_DISPATCH
+            other.rec_order = _native.RG_REC_ORDER_SEGMENT
+            assert other.ensure_packed(csr) and other.rec.shape == compact.rec.shape
+            assert other.rec_ptr.numel() == nz * ny * ((nx + 63) // 64) + 1
+            pos_o, w_o = other._record_fields(csr, 0, n_vox)
+            assert torch.equal(pos_o, pos) and torch.equal(w_o.view(torch.int32), w_back.view(torch.int32))
+            g_o = CsrGridder(geom, n_gates, nf, device=dev)
+            g_o.compact, g_o.window, g_o.packed_stream, g_o.packed = other, other.window_for(nf), True, g_r.packed
+            got.fill_(9.0)
+            g_o.apply(got, fill_value=-3.0)
+            assert torch.equal(got.view(torch.int32), rows_by_order.view(torch.int32)), ("segment order, row-wise", nf, shape)
+            g_o.tile = 384
+            got.fill_(9.0)
+            g_o.apply(got, fill_value=-3.0)
+            assert torch.equal(got.view(torch.int32), want.view(torch.int32)), ("segment order, tile kernel", nf, shape)
     # and against the float64 oracle (tolerance: float32 accumulation)
     data = fields[0].cpu().numpy()
     want64 = oracle.csr_apply_f64(indptr, gidx, wts, data, masks[0].cpu().numpy().astype(bool), shape, fill_value=-3.0)
