@@ -185,7 +185,7 @@ def csr_apply_f64(indptr, gate_indices, weights, field_values, field_mask, grid_
     return out.reshape(grid_shape)
 
 ROWWISE_TARGET = {1: 4, 2: 4, 3: 6, 4: 8}   # records per lane and row the row-wise kernel aims for, by field count
-ROWWISE_KPRE = {1: 3, 2: 3, 3: 2, 4: 3}     # records per lane and step (batch slots), by field count
+ROWWISE_KPRE = {1: 3, 2: 3, 3: 3, 4: 3}     # records per lane and step (batch slots), by field count
 ROWWISE_CHAINS = 2                          # running sums per lane and value: batch slot k adds into chain k mod 2
 
 

@@ -604,7 +604,8 @@ extern "C" int rg_csr_compact_pack(const void* indptr, int32_t indptr_is_i64, co
 // L is chosen per segment from its mean row length (kTarget records per lane and row).  This is NOT the order of
 // rg_csr_apply_f32: the two agree to float32 rounding, not bit for bit (the tile kernel over the same records, tile =
 // 384, does).
-// Per field count (measured on config 2 and the bench grid, profiles/r02_rowwise_sweep.json):
+// Per field count (measured on config 2 and the bench grid, profiles/r02_rowwise_sweep.json; three fields re-tuned in
+// round 3 after the instruction diet of the loop: 3 records per step instead of 2, -2 %, profiles/r03_cfg3_sweep.json):
 //   KPRE   records per lane and step;   kTarget  records per lane and row L aims for;
 //   kNarrow  12-byte window entries for three fields (three 4-byte LDS reads per pair instead of one 16-byte read,
 //            but a quarter less LDS per workgroup);
@@ -619,17 +620,30 @@ constexpr int kRowwiseChunksPerBlock = 1;   // consecutive chunks one workgroup 
 template <int NF> struct RowwiseConfig;
 template <> struct RowwiseConfig<1> { static constexpr int kpre = 3, target = 4; static constexpr bool narrow = false, regs = false; };
 template <> struct RowwiseConfig<2> { static constexpr int kpre = 3, target = 4; static constexpr bool narrow = false, regs = false; };
-template <> struct RowwiseConfig<3> { static constexpr int kpre = 2, target = 6; static constexpr bool narrow = true, regs = true; };
+#ifndef RG_ROWWISE_KPRE3      // A/B builds only (tools/gpu_r03_ab_slots.sh cfg3): other batch sizes / lane targets for three fields
+#define RG_ROWWISE_KPRE3 3
+#endif
+#ifndef RG_ROWWISE_TARGET3
+#define RG_ROWWISE_TARGET3 6
+#endif
+#ifndef RG_ROWWISE_REGS3
+#define RG_ROWWISE_REGS3 true
+#endif
+template <> struct RowwiseConfig<3> { static constexpr int kpre = RG_ROWWISE_KPRE3, target = RG_ROWWISE_TARGET3; static constexpr bool narrow = true, regs = RG_ROWWISE_REGS3; };
 template <> struct RowwiseConfig<4> { static constexpr int kpre = 3, target = 8; static constexpr bool narrow = false, regs = true; };
 
 // DIAG (timing-only diagnostics of tools/exp_placement4.py, results wrong by construction; one field only): bit 0 = the
 // window is not gathered (no dictionary / field reads), bit 1 = no output store, bit 2 / bit 3 = cache policy sc0 / nt on
 // the record loads, bit 4 = no record loads at all (the stream is replaced by a constant)
-#ifdef RG_ROWWISE_MIN_BLOCKS           // A/B builds only: cap the registers at what the single-chain kernel's occupancy needs
-#define RG_ROWWISE_BOUNDS __launch_bounds__(64 * kH, (NF == 1 ? 6 : NF <= 3 ? 5 : 4))
-#else
-#define RG_ROWWISE_BOUNDS __launch_bounds__(64 * kH)
+// Workgroups per CU the compiler must leave room for (= wavefronts per SIMD: a workgroup is one wavefront per SIMD), per
+// field count; 1 = no constraint.  -DRG_ROWWISE_WAVES1=.. / 3=..: A/B builds (tools/gpu_r03_ab_slots.sh occ).
+#ifndef RG_ROWWISE_WAVES1
+#define RG_ROWWISE_WAVES1 1
 #endif
+#ifndef RG_ROWWISE_WAVES3
+#define RG_ROWWISE_WAVES3 1
+#endif
+#define RG_ROWWISE_BOUNDS __launch_bounds__(64 * kH, (NF == 1 ? RG_ROWWISE_WAVES1 : NF == 3 ? RG_ROWWISE_WAVES3 : 1))
 template <typename IndT, int NF, int STRIDE, int DIAG = 0>
 __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
     const IndT* __restrict__ indptr, const int64_t* __restrict__ dict_ptr, const int32_t* __restrict__ dict, ChunkGrid cg,
@@ -721,32 +735,53 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
   }
 
   // ---- the chunk's field window + the sentinel entry ----------------------------------------------------------
+  // kFillBatch entries per thread at a time: their dictionary reads are issued back to back, then their field gathers, then
+  // the LDS stores -- two memory latencies per batch.  (Round 2 walked the entries one by one: dictionary read, wait, gather,
+  // wait, store -- 2 x 6 serialized latencies in front of the barrier on config 2's 1500-entry dictionaries, about a third
+  // of a workgroup's life.)  All loads are unconditional on clamped indices so that nothing splits the batch.
   if (windowed) {
-    for (int i = threadIdx.x; i <= nd_all; i += 64 * kH) {
-      float v[STRIDE];
-      if (i < nd_all) {
+    constexpr int kFillBatch = 4;
+    const int last_entry = nd_all > 0 ? nd_all - 1 : 0;
+    const int32_t* __restrict__ cd = nd_all > 0 ? cdict : (const int32_t*)dict_ptr;   // never dereference an empty dictionary
+    for (int i0 = threadIdx.x; i0 <= nd_all; i0 += 64 * kH * kFillBatch) {
+      unsigned gate[kFillBatch];
+#pragma unroll
+      for (int u = 0; u < kFillBatch; ++u) {
+        const int i = i0 + u * 64 * kH;
+        gate[u] = (DIAG & 1) ? 0u : (unsigned)cd[i < last_entry ? i : last_entry];
+      }
+      float v[kFillBatch][STRIDE];
+#pragma unroll
+      for (int u = 0; u < kFillBatch; ++u) {
         if constexpr (DIAG & 1) {
 #pragma unroll
-          for (int s = 0; s < STRIDE; ++s) v[s] = 1.0f;
+          for (int s = 0; s < STRIDE; ++s) v[u][s] = 1.0f;
         } else {
-          const unsigned g0 = (unsigned)cdict[i];
-          rg::load_packed<STRIDE>(packed, g0 < last_gate ? g0 : last_gate, v);
+          rg::load_packed<STRIDE>(packed, gate[u] < last_gate ? gate[u] : last_gate, v[u]);
         }
-      } else {
-#pragma unroll
-        for (int s = 0; s < STRIDE; ++s) v[s] = __builtin_bit_cast(float, RG_EXCLUDED_BITS);
       }
-      if constexpr (kNarrow) {
-        window[i * 3] = v[0]; window[i * 3 + 1] = v[1]; window[i * 3 + 2] = v[2];
-      } else if constexpr (kPremask) {
-        const bool good = rg::f32_bits(v[0]) != RG_EXCLUDED_BITS;
-        reinterpret_cast<f32x2*>(window)[i] = good ? (f32x2){v[0], 1.0f} : (f32x2){0.0f, 0.0f};
-      } else if constexpr (STRIDE == 1) {
-        window[i] = v[0];
-      } else if constexpr (STRIDE == 2) {
-        reinterpret_cast<f32x2*>(window)[i] = (f32x2){v[0], v[1]};
-      } else {
-        reinterpret_cast<f32x4*>(window)[i] = (f32x4){v[0], v[1], v[2], v[3]};
+#pragma unroll
+      for (int u = 0; u < kFillBatch; ++u) {
+        // branch-free: a thread past the end stores the sentinel into the sentinel's entry once more (same bits from every
+        // such thread), so that nothing conditional makes the compiler sink one of the batch's loads behind a wait
+        const int i_raw = i0 + u * 64 * kH;
+        const int i = i_raw < nd_all ? i_raw : nd_all;
+        if (i_raw >= nd_all) {                   // the sentinel entry: every slot EXCLUDED
+#pragma unroll
+          for (int s = 0; s < STRIDE; ++s) v[u][s] = __builtin_bit_cast(float, RG_EXCLUDED_BITS);
+        }
+        if constexpr (kNarrow) {
+          window[i * 3] = v[u][0]; window[i * 3 + 1] = v[u][1]; window[i * 3 + 2] = v[u][2];
+        } else if constexpr (kPremask) {
+          const bool good = rg::f32_bits(v[u][0]) != RG_EXCLUDED_BITS;
+          reinterpret_cast<f32x2*>(window)[i] = good ? (f32x2){v[u][0], 1.0f} : (f32x2){0.0f, 0.0f};
+        } else if constexpr (STRIDE == 1) {
+          window[i] = v[u][0];
+        } else if constexpr (STRIDE == 2) {
+          reinterpret_cast<f32x2*>(window)[i] = (f32x2){v[u][0], v[u][1]};
+        } else {
+          reinterpret_cast<f32x4*>(window)[i] = (f32x4){v[u][0], v[u][1], v[u][2], v[u][3]};
+        }
       }
     }
   }

@@ -13,24 +13,37 @@ build_variant() {   # name, flags...
   hipcc -std=c++17 -O3 --offload-arch=gfx950 -fPIC -Iinclude -I$C -ffp-contract=off "$@" -c $C/rg_csr_compact.hip -o /tmp/${TAG}_$name.o &&
   hipcc --offload-arch=gfx950 -shared -fPIC $C/rg_core.o $C/rg_csr_apply.o /tmp/${TAG}_$name.o $C/rg_products.o $C/rg_geometry.o $C/rg_roi_grid.o $C/rg_raster.o -o /tmp/${TAG}_lib$name.so
 }
-if [ "${2:-slots}" = "selects" ]; then      # the one-select + v_mul_legacy_f32 form of the masked product against round 2's two selects
+FIELDS=1,2,3,4
+if [ "${2:-slots}" = "cfg3" ]; then         # three fields: records per lane and step / per lane and row / home of the row sums
+  FIELDS=3
+  build_variant k2t4 -DRG_ROWWISE_KPRE3=2 -DRG_ROWWISE_TARGET3=4 & build_variant k3t6 -DRG_ROWWISE_KPRE3=3 -DRG_ROWWISE_TARGET3=6 &
+  build_variant k3t4 -DRG_ROWWISE_KPRE3=3 -DRG_ROWWISE_TARGET3=4 & build_variant k2t8 -DRG_ROWWISE_KPRE3=2 -DRG_ROWWISE_TARGET3=8 &
+  build_variant k2t6lds -DRG_ROWWISE_REGS3=false & build_variant k3t8 -DRG_ROWWISE_KPRE3=3 -DRG_ROWWISE_TARGET3=8 &
+  wait
+  LIBS="k2t4=/tmp/${TAG}_libk2t4.so,k3t6=/tmp/${TAG}_libk3t6.so,k3t4=/tmp/${TAG}_libk3t4.so,k2t8=/tmp/${TAG}_libk2t8.so,k2t6lds=/tmp/${TAG}_libk2t6lds.so,k3t8=/tmp/${TAG}_libk3t8.so"
+elif [ "${2:-slots}" = "occ" ]; then        # register caps: 7 wavefronts per SIMD for one field, 6 for three
+  FIELDS=1,3
+  build_variant w7 -DRG_ROWWISE_WAVES1=7 -DRG_ROWWISE_WAVES3=6 &
+  wait
+  LIBS="w7w6=/tmp/${TAG}_libw7.so"
+elif [ "${2:-slots}" = "selects" ]; then      # the one-select + v_mul_legacy_f32 form of the masked product against round 2's two selects
   build_variant twoselects -DRG_ROWWISE_TWO_SELECTS &
   wait
   LIBS="twoselects=/tmp/${TAG}_libtwoselects.so"
 else
-build_variant slots1 -DRG_ROWWISE_SLOTS=1 & build_variant slots2 -DRG_ROWWISE_SLOTS=2 & build_variant slots3cap -DRG_ROWWISE_SLOTS=3 -DRG_ROWWISE_MIN_BLOCKS & build_variant slots3 -DRG_ROWWISE_SLOTS=3 &
+build_variant slots1 -DRG_ROWWISE_SLOTS=1 & build_variant slots2 -DRG_ROWWISE_SLOTS=2 & build_variant slots3cap -DRG_ROWWISE_SLOTS=3 -DRG_ROWWISE_WAVES1=6 -DRG_ROWWISE_WAVES3=5 & build_variant slots3 -DRG_ROWWISE_SLOTS=3 &
 wait
 LIBS="slots1=/tmp/${TAG}_libslots1.so,slots2=/tmp/${TAG}_libslots2.so,slots3=/tmp/${TAG}_libslots3.so,slots3cap=/tmp/${TAG}_libslots3cap.so"
 fi
 for cfg in C2 METRIC; do
-  timeout -k 10 400 python3 tools/exp_rowwise.py --config $cfg --fields 1,2,3,4 --codes 0 --rounds 15 --libs $LIBS > gpurun_out/${TAG}_slots_${cfg}.json 2> gpurun_out/${TAG}_slots_${cfg}.log || exit 1
+  timeout -k 10 400 python3 tools/exp_rowwise.py --config $cfg --fields $FIELDS --codes 0 --rounds 15 --libs $LIBS > gpurun_out/${TAG}_slots_${cfg}.json 2> gpurun_out/${TAG}_slots_${cfg}.log || exit 1
 done
 python3 - "$TAG" <<'PY'
 import json, sys
 tag = sys.argv[1]
 for cfg in ("C2", "METRIC"):
     d = json.load(open(f"gpurun_out/{tag}_slots_{cfg}.json"))
-    for nf in (1, 2, 3, 4):
+    for nf in sorted({r["fields"] for r in d["runs"]}):
         print(cfg, f"F{nf}", {r["kernel"]: r["ms"] for r in d["runs"] if r["fields"] == nf},
               "same bits as in-tree:", [r["same_bits_as_first_row_variant"] for r in d["runs"] if r["fields"] == nf and "@" in r["kernel"]])
 PY
