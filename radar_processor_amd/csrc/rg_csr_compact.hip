@@ -737,10 +737,16 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
   // ---- the chunk's field window + the sentinel entry ----------------------------------------------------------
   // kFillBatch entries per thread at a time: their dictionary reads are issued back to back, then their field gathers, then
   // the LDS stores -- two memory latencies per batch.  (Round 2 walked the entries one by one: dictionary read, wait, gather,
-  // wait, store -- 2 x 6 serialized latencies in front of the barrier on config 2's 1500-entry dictionaries, about a third
-  // of a workgroup's life.)  All loads are unconditional on clamped indices so that nothing splits the batch.
+  // wait, store -- 2 x 6 serialized latencies in front of the barrier on config 2's 1500-entry dictionaries; other
+  // workgroups of the CU cover most of that, the batches are worth 2-5 % there.)  All loads are unconditional on clamped
+  // indices so that nothing splits the batch.  Also tried around this prologue in round 3, both slower: issuing the first
+  // step's record loads in front of the fill and holding them across it (+22 VGPRs, a wavefront of occupancy: 7-17 %
+  // slower), and throw-away loads of the same addresses to warm the L2 meanwhile (+1.4-2.8 %).
   if (windowed) {
-    constexpr int kFillBatch = 4;
+#ifndef RG_FILL_BATCH
+#define RG_FILL_BATCH 4                          // 1 / 2 / 8 measured: +2 % / +0.3 % / +0.5 % on config 2 (A/B builds)
+#endif
+    constexpr int kFillBatch = RG_FILL_BATCH;
     const int last_entry = nd_all > 0 ? nd_all - 1 : 0;
     const int32_t* __restrict__ cd = nd_all > 0 ? cdict : (const int32_t*)dict_ptr;   // never dereference an empty dictionary
     for (int i0 = threadIdx.x; i0 <= nd_all; i0 += 64 * kH * kFillBatch) {

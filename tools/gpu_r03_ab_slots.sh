@@ -21,6 +21,10 @@ if [ "${2:-slots}" = "cfg3" ]; then         # three fields: records per lane and
   build_variant k2t6lds -DRG_ROWWISE_REGS3=false & build_variant k3t8 -DRG_ROWWISE_KPRE3=3 -DRG_ROWWISE_TARGET3=8 &
   wait
   LIBS="k2t4=/tmp/${TAG}_libk2t4.so,k3t6=/tmp/${TAG}_libk3t6.so,k3t4=/tmp/${TAG}_libk3t4.so,k2t8=/tmp/${TAG}_libk2t8.so,k2t6lds=/tmp/${TAG}_libk2t6lds.so,k3t8=/tmp/${TAG}_libk3t8.so"
+elif [ "${2:-slots}" = "fill" ]; then       # entries per thread and batch of the window fill
+  build_variant fill2 -DRG_FILL_BATCH=2 & build_variant fill8 -DRG_FILL_BATCH=8 & build_variant fill1 -DRG_FILL_BATCH=1 &
+  wait
+  LIBS="fill1=/tmp/${TAG}_libfill1.so,fill2=/tmp/${TAG}_libfill2.so,fill8=/tmp/${TAG}_libfill8.so"
 elif [ "${2:-slots}" = "occ" ]; then        # register caps: 7 wavefronts per SIMD for one field, 6 for three
   FIELDS=1,3
   build_variant w7 -DRG_ROWWISE_WAVES1=7 -DRG_ROWWISE_WAVES3=6 &
