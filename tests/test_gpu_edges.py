@@ -412,7 +412,7 @@ def test_compact_csr_rich_chunks(rg):
     assert CompactCSR.build(csr3, (1, 1, 64)) is None
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(16))
 def test_compact_and_packed_kernels_fuzz(rg, seed):
     """Random hand-made CSRs -- random grid shapes (lines that are not multiples of 64 rows, planes that are not
     multiples of 4 lines), empty rows, rows longer than a tile, few or many distinct gates per chunk, int32 / int64 row
