@@ -33,13 +33,13 @@ def main():
 
     rows = []
     reads = [torch.zeros(nbytes, dtype=torch.uint8, device=dev) for _ in range(3)]
-    writes = [torch.zeros(n_blocks * 256 + (4 << 20), dtype=torch.float32, device=dev) for _ in range(6)]
+    writes = [torch.zeros(n_blocks * 264 + (4 << 20), dtype=torch.float32, device=dev) for _ in range(4)]
     for ia, a in enumerate(reads):
         ro = timed(lambda: probe.bw_read_blocked(a.data_ptr(), nbytes, block, sink.data_ptr(), stream))
         for iw, wr in enumerate(writes):
             row = {"read_array": ia, "read_address": hex(a.data_ptr()), "write_array": iw, "write_address": hex(wr.data_ptr()),
                    "read_only_ms": ro}
-            for name, mode in (("dense", 0), ("grid_layout", 1)):
+            for name, mode in (("dense", 0), ("grid_layout", 1), ("grid_layout_aligned_pieces", -1)):
                 row[name + "_ms"] = timed(lambda: probe.bw_read_blocked_write(a.data_ptr(), nbytes, block, wr.data_ptr(), 1024,
                                                                               1, mode, stream))
             rows.append(row)

@@ -76,7 +76,8 @@ __global__ __launch_bounds__(256) void read_blocked(const float4* __restrict__ a
 // (4) blocked read + a small write per workgroup: after reading its block, every `every`-th workgroup writes
 // `wbytes * every` bytes (dense: at wr + group * wbytes * every) -- the row-wise kernel's 1 KiB of grid per 68 KiB of
 // records, with the writes batched `every` workgroups at a time.  mode 1: the four 256-byte pieces of a workgroup go to
-// four lines 8000 bytes apart (the bench grid's layout) instead of one dense KiB.
+// four lines 8000 bytes apart (the bench grid's layout) instead of one dense KiB; mode -1: the same shape with every piece
+// aligned to 256 bytes (lines 8192 bytes apart); mode >= 2: spread over that many slabs.
 __global__ __launch_bounds__(256) void read_blocked_write(const float4* __restrict__ a, long n16, long block16,
                                                           float* __restrict__ wr, int wfloats, int every, int mode) {
   const long beg = (long)blockIdx.x * block16;
@@ -99,8 +100,12 @@ __global__ __launch_bounds__(256) void read_blocked_write(const float4* __restri
       const long per_slab = ((long)gridDim.x + mode - 1) / mode;
       const long piece = (long)(blockIdx.x % mode) * per_slab + blockIdx.x / mode;
       for (int k = threadIdx.x; k < wfloats; k += 256) wr[piece * wfloats + k] = acc;
-    } else {            // 4 lines x 64 floats, lines 2000 floats apart, 32 workgroups per line group
+    } else if (mode == -1) {   // the grid layout's shape with ALIGNED pieces: lines 2048 floats apart, 64 floats per piece
       const long grp = blockIdx.x / 32, col = blockIdx.x % 32;
+      const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+      wr[(grp * 4 + w) * 2048 + col * 64 + lane] = acc;
+    } else {            // 4 lines x 64 floats, lines 2000 floats apart, 32 workgroups per line group, 62-float pieces:
+      const long grp = blockIdx.x / 32, col = blockIdx.x % 32;          // every piece straddles three 128-byte lines
       const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
       wr[(grp * 4 + w) * 2000 + col * 62 + lane] = acc;
     }
