@@ -106,6 +106,9 @@ def test_bench_config5_single_gpu_line():
     assert "config 5" in line["config"]["workload"]
     assert line["value"] > 0 and line["roofline"]["kernel_ms"] > 0 and 0 < line["roofline"]["frac"] < 1
     assert line["roofline"]["ceiling_measured"] > 2000 and "traffic_source" in line["roofline"]
+    r = line["roofline"]                     # the launch-time distribution of the timed region (a mean is one draw)
+    assert r["kernel_ms_min"] <= r["kernel_ms_median"] <= r["kernel_ms_max"] and r["kernel_ms_min"] <= r["kernel_ms"] <= r["kernel_ms_max"]
+    assert r["launches_timed"] == r["launches_per_step"] * line["steps"] and line["config"]["record_order"] == "dispatch"
     assert line["end_to_end"]["ms_per_step"] > 0
 
 
@@ -116,6 +119,7 @@ def test_bench_spawns_its_own_ranks():
                        "--volumes-per-gpu", "2"])
     assert line["n_gpus"] == 2 and line["config"]["ranks_seen_by_process_group"] == 2
     assert line["config"]["volumes_total"] == 4
+    assert "skipped" in line["cpu_baseline"]            # N > 1: the host-core baseline belongs to the N = 1 line
 
 
 def test_bench_refuses_mismatched_world():
