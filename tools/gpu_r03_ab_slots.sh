@@ -21,6 +21,12 @@ if [ "${2:-slots}" = "cfg3" ]; then         # three fields: records per lane and
   build_variant k2t6lds -DRG_ROWWISE_REGS3=false & build_variant k3t8 -DRG_ROWWISE_KPRE3=3 -DRG_ROWWISE_TARGET3=8 &
   wait
   LIBS="k2t4=/tmp/${TAG}_libk2t4.so,k3t6=/tmp/${TAG}_libk3t6.so,k3t4=/tmp/${TAG}_libk3t4.so,k2t8=/tmp/${TAG}_libk2t8.so,k2t6lds=/tmp/${TAG}_libk2t6lds.so,k3t8=/tmp/${TAG}_libk3t8.so"
+elif [ "${2:-slots}" = "occ3" ]; then      # three fields: one chain and two records per step buy a wavefront of occupancy
+  FIELDS=3
+  build_variant k2c1 -DRG_ROWWISE_KPRE3=2 -DRG_ROWWISE_SLOTS=1 & build_variant k3c1 -DRG_ROWWISE_KPRE3=3 -DRG_ROWWISE_SLOTS=1 &
+  build_variant k2c1lds -DRG_ROWWISE_KPRE3=2 -DRG_ROWWISE_SLOTS=1 -DRG_ROWWISE_REGS3=false & build_variant k2c2 -DRG_ROWWISE_KPRE3=2 &
+  wait
+  LIBS="k2c1=/tmp/${TAG}_libk2c1.so,k3c1=/tmp/${TAG}_libk3c1.so,k2c1lds=/tmp/${TAG}_libk2c1lds.so,k2c2=/tmp/${TAG}_libk2c2.so"
 elif [ "${2:-slots}" = "fill" ]; then       # entries per thread and batch of the window fill
   build_variant fill2 -DRG_FILL_BATCH=2 & build_variant fill8 -DRG_FILL_BATCH=8 & build_variant fill1 -DRG_FILL_BATCH=1 &
   wait
