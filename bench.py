@@ -561,13 +561,16 @@ def run_rank(args):
             if kernel_name == "csr_compact_rowwise_kernel":
                 assert bool(torch.equal(torch.isnan(ref_out), torch.isnan(out))), "filled voxels differ from rg_csr_apply_f32"
                 scale = max(float(f_t[torch.isfinite(f_t)].abs().max()) for f_t in fields_d)
+                # |diff| <= 1e-5*|ref| + 2e-6*max|field|: north_star's relative bar plus an absolute floor three times the
+                # largest absolute error ever measured (6.1e-7*max|field|; tests/conftest.py: ATOL_FRAC)
                 excess = torch.nan_to_num((out - ref_out).abs() - 1e-5 * ref_out.abs(), nan=0.0)
                 worst = float(excess.max())
-                assert worst <= 1e-5 * scale, "row-wise kernel and reference-format kernel differ beyond 1e-5"
+                assert worst <= 2e-6 * scale, "row-wise kernel and reference-format kernel differ beyond 1e-5 rel + 2e-6 abs"
                 sig = ref_out.abs() > 1e-3 * scale
                 rel = float(((out - ref_out).abs()[sig] / ref_out.abs()[sig]).max())
+                assert rel <= 1e-5, "row-wise kernel beyond 1e-5 relative on significant voxels"
                 checked += (f"; row-wise kernel vs rg_csr_apply_f32 on all of them: same voxels filled, |diff| <= 1e-5*|ref| + "
-                            f"1e-5*max|field| everywhere (worst relative deviation where |ref| > 1e-3*max|field|: {rel:.1e})")
+                            f"2e-6*max|field| everywhere (worst relative deviation where |ref| > 1e-3*max|field|: {rel:.1e})")
                 del excess, sig
                 gridder.tile = 384                       # and the tile kernel over the very same records: bit for bit
                 gridder.apply(out)

@@ -32,7 +32,12 @@
 extern "C" {
 #endif
 
-#define RG_VERSION 100 /* 0.1.0 */
+/* ABI version: bumped whenever a signature in this header changes (an argument inserted, a meaning changed).  The Python
+ * binding (radar_processor_amd/_native.py: ABI_VERSION) refuses a library whose rg_version() differs, so a stale git-ignored
+ * .so is reported as such instead of being called with shifted arguments.  History: 100 rounds 1-2; 101 rec_order / plane0 of
+ * rg_csr_compact_pack and rg_csr_compact_apply_packed_f32 (round 3); 102 rg_csr_compact_apply_columns_f32, diagnostic tile
+ * codes refused by the product build (round 4). */
+#define RG_VERSION 102
 #define RG_MAX_FIELDS 8
 
 typedef void* rg_stream_t; /* hipStream_t */
@@ -117,8 +122,10 @@ int rg_csr_apply_f32(const void* indptr, int32_t indptr_is_i64, const int32_t* g
                      int64_t n_vox, int64_t n_pairs, int64_t line_len,
                      const float* packed, int32_t n_fields, int32_t stride, int64_t n_gates,
                      float fill_value, float* out, rg_stream_t stream);
-/* diagnostic: same kernel with a tuning variant (tile size, waves per workgroup, pipeline depth, placement) selected explicitly;
- * variant 0 is what rg_csr_apply_f32 runs.  Used only by tools/tune_k1.py for A/B timing in one process. */
+/* same kernel with the pipeline tile selected explicitly: variant = 0 (what rg_csr_apply_f32 runs) or 128, 192, 256, 320,
+ * 384, 512 pairs per step (right answers, another order of the float32 adds; used by the bit-identity tests of the compact
+ * kernels).  Anything else is RG_EINVAL in the product library; the tuning / timing-only variants of earlier rounds exist
+ * only in -DRG_EXPERIMENTS builds (tools/build_experiments.py). */
 int rg_csr_apply_f32_ex(const void* indptr, int32_t indptr_is_i64, const int32_t* gate_idx, const float* weights,
                         int64_t n_vox, int64_t n_pairs, int64_t line_len,
                         const float* packed, int32_t n_fields, int32_t stride, int64_t n_gates,
@@ -314,8 +321,9 @@ int rg_grid_filter(const void* src, int32_t data_is_f64, int64_t n, int32_t flag
  * window_cap: how many dictionary entries (of `stride` floats) a workgroup keeps in LDS (<= RG_COMPACT_MAX_WINDOW,
  * clamped to what fits next to the kernel's own LDS); chunks with a longer dictionary gather per pair from memory, so
  * any value is correct and the choice only affects speed.  tile: pairs per pipeline step, 0 = default (= the tile of
- * rg_csr_apply_f32 for the same field count; other values change the order of the float32 adds; 901-903 and
- * multiples of 1000 added to the tile are timing-only diagnostics of tools/exp_nf1.py, never used by the package).
+ * rg_csr_apply_f32 for the same field count; other values change the order of the float32 adds).  Timing-only
+ * ablations (901-909, results wrong by construction) and the block-rotation override exist only in -DRG_EXPERIMENTS builds
+ * (tools/build_experiments.py); the product library answers RG_EINVAL.
  * line_len <= 0 means one line of n_vox rows, lines_per_plane <= 0 one plane.
  * ------------------------------------------------------------------------------------------------- */
 #ifndef RG_COMPACT_LINES
@@ -360,8 +368,11 @@ int rg_csr_compact_apply_f32(const void* indptr, int32_t indptr_is_i64, const ui
  *               1.0-1.5 ms for 1-4 fields on BASELINE config 2 where the tile kernels need 1.1-3.3 ms.
  *   tile = 384  the TILE kernel of rg_csr_compact_apply_f32 over the same records: the results of rg_csr_apply_f32 for the
  *               same fields, bit for bit (576 / 768: single-field tuning variants of it).
- *   tile = 2000 + h   row-wise with a diagnostic lane split: h = 1, 2, 4 .. 64 lanes per row, or h = 70 + t to aim for t
- *               records per lane and row (another split = another order of the adds).
+ *   tile = 2000 + h   row-wise with a diagnostic lane split: h = 1, 2, 4 .. 64 lanes per row, or h = 71 .. 99 = 70 + t to
+ *               aim for t records per lane and row (another split = another order of the adds; right answers).
+ *   tile = 2100 .. 2199 (timing-only ablations: no store, no record loads ... -- WRONG results by construction) and
+ *   2201 .. 2264 (several chunks per workgroup) are compiled only into -DRG_EXPERIMENTS builds (tools/build_experiments.py);
+ *   the product library answers RG_EINVAL.
  * window_cap as for rg_csr_compact_apply_f32; the row-wise kernel keeps one entry more (an all-EXCLUDED sentinel). */
 #define RG_REC_ORDER_SEGMENT 0
 #define RG_REC_ORDER_DISPATCH 1

@@ -12,8 +12,11 @@ import threading
 from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_int64, c_uint8, c_void_p)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-# RG_LIBRARY: measurement-only override (A/B builds of the same sources with another -D, tools/gpu_r03_ab_slots.sh)
-LIB_PATH = os.environ.get("RG_LIBRARY") or os.path.join(HERE, "csrc", "libradargrid_hip.so")
+# The product loads the in-tree library and nothing else: no environment override.  Measurement scripts that want an
+# experiment build (tools/build_experiments.py) assign ``_native.LIB_PATH`` themselves before the first load; the ABI
+# check below applies to them as well.
+LIB_PATH = os.path.join(HERE, "csrc", "libradargrid_hip.so")
+ABI_VERSION = 102          # include/radargrid_hip.h: RG_VERSION -- load_library refuses a library built from another header
 
 RG_MAX_FIELDS = 8
 RG_EXCLUDED_BITS = 0x7FD1CE5D
@@ -128,6 +131,15 @@ def load_library(require_device: bool = True):
                 lib = ctypes.CDLL(LIB_PATH)
             except OSError as exc:  # missing ROCm runtime etc.
                 raise NativeUnavailable(f"cannot load {LIB_PATH}: {exc}") from exc
+            try:
+                lib.rg_version.restype = c_int32
+                built_for = int(lib.rg_version())
+            except AttributeError:
+                raise NativeUnavailable(f"{LIB_PATH} does not export rg_version") from None
+            if built_for != ABI_VERSION:
+                raise NativeUnavailable(
+                    f"{LIB_PATH} was built from header version {built_for}, this package binds version {ABI_VERSION}: the "
+                    "signatures differ, calling it would shift arguments. Rebuild it with `python -m radar_processor_amd.build`.")
             for name, (restype, argtypes) in SIGNATURES.items():
                 try:
                     fn = getattr(lib, name)

@@ -53,9 +53,8 @@ def _stale(target: str, deps: List[str]) -> bool:
 def build(force: bool = False, verbose: bool = True) -> str:
     """Compile every HIP source for gfx950 and link the shared library. Returns its path."""
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "rg_common.hpp"), os.path.join(CSRC, "rg_roi_search.hpp"),
-               os.path.join(CSRC, "rg_row_phase.hpp"),
-               os.path.join(INCLUDE, "radargrid_hip.h")]
+    headers = ([os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".hpp")]
+               + [os.path.join(INCLUDE, "radargrid_hip.h")])
     common = ["-std=c++17", "-O3", f"--offload-arch={ARCH}", "-fPIC",
               f"-I{INCLUDE}", f"-I{CSRC}", "-Wall", "-Wno-unused-result", *COMMON_FLAGS]
     objs, jobs = [], []
@@ -81,23 +80,59 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+    with open(STAMP_PATH, "w") as f:       # what this library was compiled from (ensure_built compares it)
+        f.write(source_digest() + "\n")
     return LIB_PATH
 
 
+def sources_and_headers() -> List[str]:
+    """Every file the library is compiled from."""
+    return ([os.path.join(CSRC, src) for src, _ in SOURCES if os.path.exists(os.path.join(CSRC, src))]
+            + [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".hpp")]
+            + [os.path.join(INCLUDE, "radargrid_hip.h")])
+
+
+STAMP_PATH = LIB_PATH + ".stamp"
+
+
+def source_digest() -> str:
+    """sha256 over the names and CONTENTS of every source and header plus the compile flags: what the library was built
+    from.  Contents, not time stamps -- a snapshot copy or a checkout may reorder mtimes without changing a byte."""
+    import hashlib
+    h = hashlib.sha256()
+    h.update(repr((ARCH, COMMON_FLAGS, [(s, e) for s, e in SOURCES])).encode())
+    for path in sources_and_headers():
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def is_stale() -> bool:
+    """The library is missing, or was built from other sources / headers than the ones in the tree now (its stamp file
+    holds the digest of what it was compiled from)."""
+    if not os.path.exists(LIB_PATH) or not os.path.exists(STAMP_PATH):
+        return True
+    with open(STAMP_PATH) as f:
+        return f.read().strip() != source_digest()
+
+
 def ensure_built(verbose: bool = True) -> str:
-    """Build the library only when it is not there at all (a checkout without the git-ignored ``.so``).  Called by
-    the entry points that own a process -- tests, ``bench.py``, ``smoke()`` -- never by the product path, which keeps
-    failing loudly when the library is missing."""
-    if not os.path.exists(LIB_PATH):
+    """Build the library when it is missing OR was compiled from other sources / headers than the tree holds now (a
+    git-ignored ``.so`` left over from an earlier revision would otherwise be used silently).  Called by the entry points
+    that own a process -- tests, ``bench.py``, ``smoke()`` -- never by the product path, which keeps failing loudly when
+    the library is missing and refuses a library of another ABI version (``_native.load_library``)."""
+    if is_stale():
         import fcntl
         # several ranks of one node may get here together: one compiles, the others wait on the lock and find it built
         with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
             fcntl.flock(lock, fcntl.LOCK_EX)
             try:
-                if not os.path.exists(LIB_PATH):
+                if is_stale():
                     if verbose:
-                        print(f"[build] {LIB_PATH} is missing: compiling it now (hipcc, {ARCH})", flush=True)
-                    build(verbose=verbose)
+                        what = "is missing" if not os.path.exists(LIB_PATH) else "was built from other sources"
+                        print(f"[build] {LIB_PATH} {what}: compiling it now (hipcc, {ARCH})", flush=True)
+                    build(force=os.path.exists(LIB_PATH), verbose=verbose)
             finally:
                 fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH

@@ -268,12 +268,12 @@ int dispatch(int nf, int variant, const void* indptr, const int32_t* gidx, const
   // (tools/tune_k1.py).
   if (nf == 1) {
     switch (variant) {
+#ifdef RG_EXPERIMENTS   // tuning variants and the timing-only ablation: experiment builds (tools/build_experiments.py) only
       case 8: return RG_KD(1, 1, 512, kXcdSlab, 0);       // XCD placement
       case 16: return RG_KD(1, 1, 512, kXcdGroup, 0);
-      case 128: return RG_KD(1, 1, 128, kXcdNone, 0);
-      case 256: case 18: return RG_KD(1, 1, 256, kXcdNone, 0);      // tile size
+      case 18: return RG_KD(1, 1, 256, kXcdNone, 0);
       case 23: return RG_KD(1, 1, 448, kXcdNone, 0);
-      case 512: case 9: return RG_KD(1, 1, 512, kXcdNone, 0);
+      case 9: return RG_KD(1, 1, 512, kXcdNone, 0);
       case 17: return RG_KD(1, 1, 640, kXcdNone, 0);
       case 19: return RG_KD(1, 1, 512, kXcdNone, kWpb1);  // waves per workgroup
       case 20: return RG_KD(1, 1, 512, kXcdNone, kWpb2);
@@ -281,7 +281,11 @@ int dispatch(int nf, int variant, const void* indptr, const int32_t* gidx, const
       case 22: return RG_KD(1, 1, 512, kXcdNone, kStages3);   // three CSR tiles in flight
       case 24: return RG_KD(1, 1, 384, kXcdNone, kStages3);
       case 25: return RG_KD(1, 1, 256, kXcdNone, kStages3);
-      case 28: return RG_KD(1, 1, 512, kXcdNone, kNoGather);  // timing-only ablation: no field gather
+      case 28: return RG_KD(1, 1, 512, kXcdNone, kNoGather);  // timing-only ablation: no field gather (wrong results)
+#endif
+      case 128: return RG_KD(1, 1, 128, kXcdNone, 0);     // pipeline tile (right answers; another order of the float32 adds)
+      case 256: return RG_KD(1, 1, 256, kXcdNone, 0);
+      case 512: return RG_KD(1, 1, 512, kXcdNone, 0);
       default: return RG_KD(1, 1, 384, kXcdNone, 0);   // 384-pair tiles: same speed as 512 or slightly better, 72 VGPRs
     }
   }
@@ -340,6 +344,11 @@ extern "C" int rg_csr_apply_f32_ex(const void* indptr, int32_t indptr_is_i64, co
              (long)n_gates, stride);
   RG_REQUIRE(n_vox <= 0x3FFFFFFFFFL, RG_EUNSUPPORTED, "rg_csr_apply_f32: n_vox too large for one launch");
   RG_REQUIRE(rg::aligned16(packed), RG_EALIGN, "rg_csr_apply_f32: packed must be 16-byte aligned");
+#ifndef RG_EXPERIMENTS
+  RG_REQUIRE(variant == 0 || variant == 128 || variant == 192 || variant == 256 || variant == 320 || variant == 384 ||
+                 variant == 512, RG_EINVAL,
+             "rg_csr_apply_f32_ex: variant must be 0 (default) or a pipeline tile of 128, 192, 256, 320, 384 or 512 pairs");
+#endif
   if (n_vox == 0) return RG_OK;
   if (line_len <= 0) line_len = n_vox;   // no grid lines known: one line, plain 64-row segments
   RG_REQUIRE(n_vox % line_len == 0, RG_EINVAL, "rg_csr_apply_f32: n_vox=%ld is not a multiple of line_len=%ld",

@@ -372,6 +372,7 @@ int launch(int nf, int tile, int window_cap, const void* indptr, const uint16_t*
   switch (nf) {
     case 1:
       switch (tile) {
+#ifdef RG_EXPERIMENTS   // timing-only ablations (tools/exp_nf1.py): results wrong by construction, never in the product library
         case 901: return launch_nf<IndT, 1, 384, 1>(window_cap, indptr, lidx, wts, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s);
         case 902: return launch_nf<IndT, 1, 384, 2>(window_cap, indptr, lidx, wts, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s);
         case 903: return launch_nf<IndT, 1, 384, 3>(window_cap, indptr, lidx, wts, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s);
@@ -381,6 +382,7 @@ int launch(int nf, int tile, int window_cap, const void* indptr, const uint16_t*
         case 906: return launch_nf<IndT, 1, 384, 0, 1>(window_cap, indptr, lidx, wts, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s);
         case 907: return launch_nf<IndT, 1, 384, 0, 3>(window_cap, indptr, lidx, wts, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s);
         case 908: return launch_nf<IndT, 1, 512, 3>(window_cap, indptr, lidx, wts, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s);
+#endif
         case 128: return RG_K1C(1, 128);
         case 256: return RG_K1C(1, 256);
         case 512: return RG_K1C(1, 512);
@@ -462,11 +464,16 @@ extern "C" int rg_csr_compact_apply_f32(const void* indptr, int32_t indptr_is_i6
              "rg_csr_compact_apply_f32: pairs present but local_idx/weights/dict/packed/n_gates missing");
   RG_REQUIRE(n_gates <= 0x7FFFFFFFL, RG_EUNSUPPORTED, "rg_csr_compact_apply_f32: n_gates exceeds int32 gate indices");
   RG_REQUIRE(n_vox <= 0x3FFFFFFFFFL, RG_EUNSUPPORTED, "rg_csr_compact_apply_f32: n_vox too large for one launch");
+#ifdef RG_EXPERIMENTS
   const int32_t rot_override = tile / 1000;   // diagnostic: tile = 1000 * rotation + tile selects the block rotation
   tile %= 1000;
-  RG_REQUIRE(tile == 0 || tile == 128 || tile == 192 || tile == 256 || tile == 320 || tile == 384 || tile == 512 ||
-                 (tile >= 901 && tile <= 909), RG_EINVAL,
-             "rg_csr_compact_apply_f32: tile must be 0 (default), 128, 192, 256, 320, 384 or 512");
+  const bool ablation = tile >= 901 && tile <= 909;
+#else
+  const int32_t rot_override = 0;
+  const bool ablation = false;
+#endif
+  RG_REQUIRE(tile == 0 || tile == 128 || tile == 192 || tile == 256 || tile == 320 || tile == 384 || tile == 512 || ablation,
+             RG_EINVAL, "rg_csr_compact_apply_f32: tile must be 0 (default), 128, 192, 256, 320, 384 or 512");
   RG_REQUIRE(window_cap >= 0 && window_cap <= RG_COMPACT_MAX_WINDOW, RG_EINVAL,
              "rg_csr_compact_apply_f32: window_cap %d outside 0..%d", window_cap, RG_COMPACT_MAX_WINDOW);
   RG_REQUIRE(rg::aligned16(packed), RG_EALIGN, "rg_csr_compact_apply_f32: packed must be 16-byte aligned");
@@ -620,13 +627,18 @@ constexpr int kRowwiseChunksPerBlock = 1;   // consecutive chunks one workgroup 
 template <int NF> struct RowwiseConfig;
 template <> struct RowwiseConfig<1> { static constexpr int kpre = 3, target = 4; static constexpr bool narrow = false, regs = false; };
 template <> struct RowwiseConfig<2> { static constexpr int kpre = 3, target = 4; static constexpr bool narrow = false, regs = false; };
-#ifndef RG_ROWWISE_KPRE3      // A/B builds only (tools/gpu_r03_ab_slots.sh cfg3): other batch sizes / lane targets for three fields
+// Tuning knobs of three fields: fixed in the product library; -DRG_EXPERIMENTS builds (tools/build_experiments.py) may
+// override them with -DRG_ROWWISE_KPRE3=.. etc. for A/B measurements.
+#if !defined(RG_EXPERIMENTS) || !defined(RG_ROWWISE_KPRE3)
+#undef RG_ROWWISE_KPRE3
 #define RG_ROWWISE_KPRE3 3
 #endif
-#ifndef RG_ROWWISE_TARGET3
+#if !defined(RG_EXPERIMENTS) || !defined(RG_ROWWISE_TARGET3)
+#undef RG_ROWWISE_TARGET3
 #define RG_ROWWISE_TARGET3 6
 #endif
-#ifndef RG_ROWWISE_REGS3
+#if !defined(RG_EXPERIMENTS) || !defined(RG_ROWWISE_REGS3)
+#undef RG_ROWWISE_REGS3
 #define RG_ROWWISE_REGS3 true
 #endif
 template <> struct RowwiseConfig<3> { static constexpr int kpre = RG_ROWWISE_KPRE3, target = RG_ROWWISE_TARGET3; static constexpr bool narrow = true, regs = RG_ROWWISE_REGS3; };
@@ -637,10 +649,12 @@ template <> struct RowwiseConfig<4> { static constexpr int kpre = 3, target = 8;
 // the record loads, bit 4 = no record loads at all (the stream is replaced by a constant)
 // Workgroups per CU the compiler must leave room for (= wavefronts per SIMD: a workgroup is one wavefront per SIMD), per
 // field count; 1 = no constraint.  -DRG_ROWWISE_WAVES1=.. / 3=..: A/B builds (tools/gpu_r03_ab_slots.sh occ).
-#ifndef RG_ROWWISE_WAVES1
+#if !defined(RG_EXPERIMENTS) || !defined(RG_ROWWISE_WAVES1)
+#undef RG_ROWWISE_WAVES1
 #define RG_ROWWISE_WAVES1 1
 #endif
-#ifndef RG_ROWWISE_WAVES3
+#if !defined(RG_EXPERIMENTS) || !defined(RG_ROWWISE_WAVES3)
+#undef RG_ROWWISE_WAVES3
 #define RG_ROWWISE_WAVES3 1
 #endif
 #define RG_ROWWISE_BOUNDS __launch_bounds__(64 * kH, (NF == 1 ? RG_ROWWISE_WAVES1 : NF == 3 ? RG_ROWWISE_WAVES3 : 1))
@@ -743,7 +757,8 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
   // step's record loads in front of the fill and holding them across it (+22 VGPRs, a wavefront of occupancy: 7-17 %
   // slower), and throw-away loads of the same addresses to warm the L2 meanwhile (+1.4-2.8 %).
   if (windowed) {
-#ifndef RG_FILL_BATCH
+#if !defined(RG_EXPERIMENTS) || !defined(RG_FILL_BATCH)
+#undef RG_FILL_BATCH
 #define RG_FILL_BATCH 4                          // 1 / 2 / 8 measured: +2 % / +0.3 % / +0.5 % on config 2 (A/B builds)
 #endif
     constexpr int kFillBatch = RG_FILL_BATCH;
@@ -853,7 +868,7 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
     // 8.051 vs 8.050 ms, same process and arrays; <= 1.3 % for 2-4 fields).  One chain per slot (three) reaches 4.3e-6 --
     // exact sums would give 4.2e-6, the reference's own rounding -- but costs a wavefront of occupancy (75 -> 89 VGPRs for
     // one field): +2.1 % on the bench grid, +10 / +21 % for two / four fields (profiles/r03_slots_ab.json).
-#ifdef RG_ROWWISE_SLOTS                 // A/B builds only (tools/gpu_r03_ab_slots.sh): 1 = round 2's one chain per lane
+#if defined(RG_EXPERIMENTS) && defined(RG_ROWWISE_SLOTS)   // A/B builds only: 1 = round 2's one chain per lane
     constexpr int KS = RG_ROWWISE_SLOTS < KPRE ? RG_ROWWISE_SLOTS : KPRE;
 #else
     constexpr int KS = 2;
@@ -919,7 +934,7 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
           // ONE select per field and pair: the effective weight is w or +0, and v_mul_legacy_f32 makes 0 * sentinel = +0
           // where an IEEE multiply would make NaN (for a non-zero weight the two multiplies are the same operation, so
           // unmasked NaN / Inf data propagates exactly as before: same bits as good ? w * v : 0)
-#ifdef RG_ROWWISE_TWO_SELECTS            // A/B builds only: round 2's form of the same arithmetic
+#if defined(RG_EXPERIMENTS) && defined(RG_ROWWISE_TWO_SELECTS)   // A/B builds only: round 2's form of the same arithmetic
           ap[k % KS][f] += good ? w[i] * v[f] : 0.0f;
           aw[k % KS][f] += good ? w[i] : 0.0f;
 #else
@@ -1048,6 +1063,7 @@ int launch_rowwise_nf(int nf, int window_cap, const void* indptr, const int64_t*
 #define RG_ROW(NF_) \
   launch_rowwise<IndT, NF_>(window_cap, indptr, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s, ps, lanes_hint, cpb)
   int cpb = 0;
+#ifdef RG_EXPERIMENTS
   if (lanes_hint >= 200 && lanes_hint <= 264) {                // tile = 2200 + n: n consecutive chunks per workgroup
     cpb = lanes_hint - 200;
     lanes_hint = 0;
@@ -1066,6 +1082,7 @@ int launch_rowwise_nf(int nf, int window_cap, const void* indptr, const int64_t*
     }
 #undef RG_DIAG
   }
+#endif
   switch (nf) {
     case 1: return RG_ROW(1);
     case 2: return RG_ROW(2);
@@ -1090,10 +1107,14 @@ extern "C" int rg_csr_compact_apply_packed_f32(const void* indptr, int32_t indpt
                                                int32_t window_cap, int32_t tile, rg_stream_t stream) {
   const bool rowwise = tile == 0 || tile >= 2000;
   const int lanes_hint = tile >= 2000 ? tile - 2000 : 0;
+#ifdef RG_EXPERIMENTS   // 2100 + DIAG bits (timing-only, wrong results) and 2200 + chunks per workgroup: experiment builds only
+  const bool experiment = (lanes_hint >= 100 && lanes_hint < 200) || (lanes_hint >= 201 && lanes_hint <= 264);
+#else
+  const bool experiment = false;
+#endif
   RG_REQUIRE(tile == 0 || tile == 384 || ((tile == 576 || tile == 768) && n_fields == 1) ||
                  (tile >= 2000 && ((lanes_hint >= 1 && lanes_hint <= 64 && (lanes_hint & (lanes_hint - 1)) == 0) ||
-                                   (lanes_hint > 70 && lanes_hint <= 99) || (lanes_hint >= 100 && lanes_hint < 200) ||
-                                   (lanes_hint >= 201 && lanes_hint <= 264))),
+                                   (lanes_hint > 70 && lanes_hint <= 99) || experiment)),
              RG_EINVAL,
              "rg_csr_compact_apply_packed_f32: tile must be 0 (row-wise kernel), 384 (tile kernel; one field: also 576 / "
              "768) or 2000 + lane split");

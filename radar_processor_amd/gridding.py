@@ -176,12 +176,13 @@ class CsrGridder:
                 _native.ptr(csr.indptr), int(csr.is_i64), _native.ptr(c.local_idx), _native.ptr(csr.weights),
                 _native.ptr(c.dict_ptr), _native.ptr(c.dict), self.n_vox, csr.n_pairs, nx, ny, _native.ptr(self.packed),
                 self.n_fields, self.stride, self.n_gates, float(np.float32(fill_value)), _native.ptr(out), self.window,
-                self.tile, _native.stream_ptr()), "rg_csr_compact_apply_f32")
+                self.tile if self.tile in _PIPELINE_TILES else 0, _native.stream_ptr()), "rg_csr_compact_apply_f32")
             return
         _native.check(self.lib.rg_csr_apply_f32_ex(
             _native.ptr(csr.indptr), int(csr.is_i64), _native.ptr(csr.gate_indices), _native.ptr(csr.weights),
             self.n_vox, csr.n_pairs, nx, _native.ptr(self.packed), self.n_fields, self.stride, self.n_gates,
-            float(np.float32(fill_value)), _native.ptr(out), self.tile, _native.stream_ptr()), "rg_csr_apply_f32")
+            float(np.float32(fill_value)), _native.ptr(out), self.tile if self.tile in _PIPELINE_TILES else 0,
+            _native.stream_ptr()), "rg_csr_apply_f32")
 
     def algorithmic_bytes(self) -> int:
         """Bytes one ``apply`` launch must move: index + weight per pair, the row pointers,
@@ -205,6 +206,7 @@ class CsrGridder:
                 + self.n_fields * (5 * self.n_gates + 4 * self.n_vox))
 
 
+_PIPELINE_TILES = (128, 192, 256, 320, 384, 512)   # pairs per pipeline step the tile kernels accept (0 = their default)
 _COMPACT_MIN_PAIRS = 50_000_000     # below this a pass takes well under a millisecond either way
 _COMPACT_MAX_WINDOW_BYTES = 24576  # LDS window beyond which the standard kernel is the faster one (CsrGridder.__init__)
 _COMPACT_MAX_FALLBACK = 0.02        # share of pairs allowed on the per-pair path before the standard kernel is preferred

@@ -94,10 +94,19 @@ def has_gpu():
         return False
 
 
-def assert_same_to_rounding(got, want, scale, fill=None, rtol=1e-5):
+# Absolute floor of the gridded-value comparisons, as a fraction of max|field|: a weighted mean of mixed-sign data that
+# cancels to ~0 has no relative floor, so "<= 1e-5 relative" (north_star) needs one.  The largest absolute error ever
+# measured between this build and the reference / the oracle is 6.1e-7 * max|field| (round 3,
+# gpurun_out/parity_relerr_fullsize.json); the floor is set three times above that, not at the 1e-5 of rounds 1-3, which
+# was 16x looser than the code.  A failure at this floor is a finding to report, not a reason to loosen it.
+ATOL_FRAC = 2e-6
+RTOL = 1e-5
+
+
+def assert_same_to_rounding(got, want, scale, fill=None, rtol=RTOL, atol_frac=ATOL_FRAC):
     """Two grids summed in different float32 orders (the row-wise kernel against the tile kernels / the oracle): the same
-    voxels filled, and every value within ``rtol * |want| + rtol * scale`` (``scale`` = the largest |value| of the field:
-    a weighted mean of mixed-sign data that cancels has no relative floor).  Accepts numpy arrays or torch tensors."""
+    voxels filled, and every value within ``rtol * |want| + atol_frac * scale`` (``scale`` = the largest |value| of the
+    field).  Accepts numpy arrays or torch tensors."""
     if hasattr(got, "detach"):
         got = got.detach().cpu().numpy()
     if hasattr(want, "detach"):
@@ -106,4 +115,4 @@ def assert_same_to_rounding(got, want, scale, fill=None, rtol=1e-5):
         np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
     else:
         np.testing.assert_array_equal(got == np.float32(fill), want == np.float32(fill))
-    np.testing.assert_allclose(got, want, rtol=rtol, atol=rtol * float(scale), equal_nan=True)
+    np.testing.assert_allclose(got, want, rtol=rtol, atol=atol_frac * float(scale), equal_nan=True)

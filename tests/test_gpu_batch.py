@@ -14,7 +14,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import REPO
+from conftest import ATOL_FRAC, REPO
 from oracle import radar_grid_oracle as oracle
 
 pytestmark = pytest.mark.gpu
@@ -69,7 +69,7 @@ def test_volume_batch_grid_shard_under_rccl(nccl_group, tmp_path):
                 g = got[b][i].cpu().numpy()
                 np.testing.assert_array_equal(np.isnan(g), np.isnan(want))
                 scale = float(np.abs(data[np.isfinite(data) & ~mask]).max())
-                np.testing.assert_allclose(g, want, rtol=1e-5, atol=1e-5 * scale, equal_nan=True)
+                np.testing.assert_allclose(g, want, rtol=1e-5, atol=ATOL_FRAC * scale, equal_nan=True)
     planes = vb.grid_shard(volumes, products=lambda g: rg.column_max(g[0]))
     local = torch.stack([planes[b] for b in range(5)])
     mine = torch.where(torch.isnan(local), torch.full_like(local, float("-inf")), local).amax(dim=0)

@@ -456,6 +456,10 @@ def test_compact_and_packed_kernels_fuzz(rg, seed):
     fields = [torch.from_numpy(rng.normal(10, 20, n_gates).astype(np.float32)).to(dev) for _ in range(4)]
     masks = [torch.from_numpy((rng.random(n_gates) < 0.2).astype(np.uint8)).to(dev) if k % 2 == 0 else None for k in range(4)]
     fields[1][::7] = float("nan")                                      # unmasked NaN propagates like in NumPy
+    fields[1][3::11] = float("inf")                                    # ... and so do unmasked infinities (Inf - Inf = NaN)
+    fields[1][5::13] = float("-inf")
+    fields[1][1::17] = 1e-40                                           # a denormal value: the product is not flushed
+    fields[0][2::19] = -0.0
     for nf in (1, 2, 3, 4):
         g_s = CsrGridder(geom, n_gates, nf, device=dev)
         g_p = CsrGridder(geom, n_gates, nf, device=dev)
@@ -501,13 +505,6 @@ def test_compact_and_packed_kernels_fuzz(rg, seed):
             live = ~np.isnan(emu)
             assert np.array_equal(got_np.view(np.int32)[live], emu.view(np.int32)[live]), ("row-wise order", nf, hint, shape)
         g_r.tile = 0
-        # several consecutive chunks per workgroup (tile = 2200 + n; the window is refilled behind a barrier): the same bits
-        for cpw in (2, 5):
-            g_r.tile = 2200 + cpw
-            got.fill_(9.0)
-            g_r.apply(got, fill_value=-3.0)
-            assert torch.equal(got.view(torch.int32), row.view(torch.int32)), ("chunks per workgroup", cpw, nf, shape)
-        g_r.tile = 0
         rows_by_order = row
         # the OTHER record order (line-major segments instead of dispatch order): other slots, the same records, the same bits
         # from both kernels, and the same positions and weights decoded
@@ -538,3 +535,81 @@ def test_compact_and_packed_kernels_fuzz(rg, seed):
     out1 = torch.empty((1, n_vox), dtype=torch.float32, device=dev)
     g1.apply(out1, fill_value=-3.0)
     np.testing.assert_allclose(out1.cpu().numpy().reshape(shape), want64, rtol=2e-6, atol=2e-6 * 100.0)
+
+
+def test_nonfinite_and_denormal_values_bit_for_bit_across_kernels(rg):
+    """Unmasked +/-Inf, NaN, -0.0 and denormal gate values (interpolate.py:78-82 lets them all through: only MASKED gates
+    are dropped) on rows of one or two pairs -- where the order of the float32 adds cannot matter -- so every kernel
+    must return the same BITS as NumPy's arithmetic: K1, the tile kernel over the packed records and the row-wise kernel
+    (whose masked product is v_mul_legacy_f32 with one select: 0 * x = +0 only for an excluded gate, the IEEE product
+    otherwise -- the packed weights are never 0: a zero weight is not codable and falls back to the plain arrays)."""
+    import torch
+    from radar_processor_amd.gridding import CsrGridder
+    from radar_processor_amd.grid_geometry import DeviceCSR, GridGeometry
+    dev = torch.device("cuda")
+    inf, nan = np.float32("inf"), np.float32("nan")
+    den = np.float32(1e-40)                                            # subnormal in float32
+    assert 0 < den < np.finfo(np.float32).tiny
+    #            0     1     2      3     4     5     6     7          8
+    vals = np.array([inf, -inf, nan, -0.0, den, 5.0, -den, 3.0e38, 2.5], dtype=np.float32)
+    mask = np.zeros(9, dtype=bool)
+    mask[8] = True                                                     # an excluded gate next to the special ones
+    rows = [[0], [1], [0, 1], [2, 5], [3], [3, 3], [4], [4, 6], [4, 4], [7, 7], [0, 8], [8], [5, 8], [4, 8], [6], []]
+    lengths = np.array([len(r) for r in rows])
+    indptr = np.zeros(len(rows) + 1, dtype=np.int64)
+    np.cumsum(lengths, out=indptr[1:])
+    gidx = np.array([g for r in rows for g in r], dtype=np.int32)
+    wts = np.array([1.0, 0.5, 0.25, 0.75, 1.0 + 1e-5, 0.0183, 0.3][: 7] * 4, dtype=np.float32)[: gidx.size]
+    shape = (1, 1, len(rows))
+    want = oracle.csr_apply(indptr, gidx, wts, vals, mask, shape, fill_value=-9.0).reshape(-1)
+    with np.errstate(all="ignore"):
+        assert np.isposinf(want[0]) and np.isneginf(want[1]) and np.isnan(want[2]) and np.isnan(want[3])
+        assert want[4] == 0 and np.signbit(want[4]) and 0 < want[6] < np.finfo(np.float32).tiny
+        assert want[11] == -9.0 and want[15] == -9.0
+    csr = DeviceCSR(torch.from_numpy(indptr.astype(np.int32)).to(dev), torch.from_numpy(gidx).to(dev),
+                    torch.from_numpy(wts).to(dev), int(gidx.max()))
+    geom = GridGeometry.from_device(shape, ((0.0, 1.0),) * 3, csr, 17000.0)
+    compact = geom.device_compact(dev)
+    assert compact is not None and compact.ensure_packed(csr)
+    f_t, m_t = torch.from_numpy(vals).to(dev), torch.from_numpy(mask.astype(np.uint8)).to(dev)
+    got = {}
+    for name, tile, use_compact in (("K1", 0, False), ("tile", 384, True), ("rowwise", 0, True)):
+        g = CsrGridder(geom, vals.size, 1, device=dev)
+        if use_compact:
+            g.compact, g.window, g.packed_stream, g.tile = compact, compact.window_for(1), True, tile
+        g.pack([f_t], [m_t])
+        out = torch.full((1, len(rows)), 7.0, dtype=torch.float32, device=dev)
+        g.apply(out, fill_value=-9.0)
+        got[name] = out.cpu().numpy().reshape(-1)
+    for name, arr in got.items():
+        np.testing.assert_array_equal(np.isnan(arr), np.isnan(want), err_msg=name)
+        live = ~np.isnan(want)
+        assert np.array_equal(arr.view(np.int32)[live], want.view(np.int32)[live]), (name, arr, want)
+
+
+def test_product_library_refuses_timing_only_and_experiment_tile_codes(rg):
+    """The shipped library computes right answers or refuses: the timing-only variants of the row-wise kernel (tile = 2100 +
+    bits: no store, no record loads, ...), several chunks per workgroup (2201 .. 2264), the ablations of the tile kernel
+    (901 .. 909, block-rotation overrides) and K1's tuning variants exist only in -DRG_EXPERIMENTS builds
+    (tools/build_experiments.py)."""
+    import torch
+    from radar_processor_amd import _native
+    lib = rg.load_library()
+    dev = torch.device("cuda")
+    ip = torch.zeros(65, dtype=torch.int32, device=dev)
+    buf = torch.zeros(64, dtype=torch.float32, device=dev)
+    i64 = torch.zeros(8, dtype=torch.int64, device=dev)
+    rec = torch.zeros((4, 4), dtype=torch.int32, device=dev)
+    P = _native.ptr
+    for tile in (2100, 2102, 2116, 2199, 2201, 2204, 2264, 2265, 1999, 385):
+        st = lib.rg_csr_compact_apply_packed_f32(P(ip), 0, P(rec), P(i64), _native.RG_REC_ORDER_DISPATCH, 120 << 23, P(i64),
+                                                 P(ip), 64, 0, 64, 1, P(buf), 1, 1, 64, 0.0, P(buf), 256, tile, 0)
+        assert st == _native.RG_EINVAL, (tile, st)
+    for tile in (901, 903, 909, 5384, 1000):
+        st = lib.rg_csr_compact_apply_f32(P(ip), 0, P(ip), P(buf), P(i64), P(ip), 64, 0, 64, 1, P(buf), 1, 1, 64, 0.0, P(buf),
+                                          256, tile, 0)
+        assert st == _native.RG_EINVAL, (tile, st)
+    for variant in (8, 9, 16, 19, 22, 28, 640):
+        st = lib.rg_csr_apply_f32_ex(P(ip), 0, P(ip), P(buf), 64, 0, 64, P(buf), 1, 1, 64, 0.0, P(buf), variant, 0)
+        assert st == _native.RG_EINVAL, (variant, st)
+    torch.cuda.synchronize()

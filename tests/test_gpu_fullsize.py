@@ -9,7 +9,7 @@ these sizes in seconds):
 import numpy as np
 import pytest
 
-from conftest import assert_same_to_rounding
+from conftest import ATOL_FRAC, assert_same_to_rounding
 from oracle import radar_grid_oracle as oracle
 
 pytestmark = pytest.mark.gpu
@@ -124,7 +124,7 @@ def test_c2_products_consistency_and_oracle_rows(c2):
         want = oracle.csr_apply(ip - ip[0], idx, w, data, mask, (1, 1, nx))[0, 0]
         got = grid[iz, iy].cpu().numpy()
         np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
-        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5 * 75.0, equal_nan=True)
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=ATOL_FRAC * 75.0, equal_nan=True)
         # and the builder's rows against the brute-force oracle on a 4-voxel window of this row
         limits = c2["cfg"]["grid_limits"]
         xc = np.linspace(limits[2][0], limits[2][1], nx, dtype="float32")
@@ -319,7 +319,7 @@ def test_c3_fused_pass_against_oracle_rows_with_the_error_tail(c2):
             want = oracle.csr_apply(ip - ip[0], idx, w, data, mask, (1, 1, nx))[0, 0]
             got = grid[k, iz, iy].cpu().numpy()
             np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
-            np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5 * scale, equal_nan=True)
+            np.testing.assert_allclose(got, want, rtol=1e-5, atol=ATOL_FRAC * scale, equal_nan=True)
             filled = np.isfinite(want)
             err = np.abs(got[filled].astype(np.float64) - want[filled].astype(np.float64))
             mag = np.abs(want[filled].astype(np.float64))
@@ -581,7 +581,7 @@ def test_metric_compact_kernels_match_reference_format(metric):
     scale = float(f[torch.isfinite(f) & (metric["m"] == 0)].abs().max())
     assert bool(torch.equal(torch.isnan(k1), torch.isnan(k1c)))
     err = (k1c - k1).abs() - 1e-5 * k1.abs()
-    assert float(torch.nan_to_num(err, nan=0.0).max()) <= 1e-5 * scale
+    assert float(torch.nan_to_num(err, nan=0.0).max()) <= ATOL_FRAC * scale
     del err
     again = torch.full_like(k1c, -7.0)
     metric["g_c"].pack([f], [metric["m"]])
@@ -688,7 +688,7 @@ def test_metric_oracle_rows_beyond_2_31(metric):
         for got_t in (k1, k1c):
             got = got_t[0, v0:v0 + nx].cpu().numpy()
             np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
-            np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5 * scale, equal_nan=True)
+            np.testing.assert_allclose(got, want, rtol=1e-5, atol=ATOL_FRAC * scale, equal_nan=True)
         checked_pairs += int(ip[-1] - ip[0])
         for ix0 in (37, 1000, 1960):
             sub = ((float(zc[iz]), float(zc[iz])), (float(yc[iy]), float(yc[iy])), (float(xc[ix0]), float(xc[ix0 + 3])))

@@ -11,6 +11,7 @@ are torn down before this one allocates."""
 import numpy as np
 import pytest
 
+from conftest import ATOL_FRAC
 from oracle import radar_grid_oracle as oracle
 
 pytestmark = pytest.mark.gpu
@@ -163,7 +164,7 @@ def test_c4_oracle_rows_including_the_radar_column(c4):
         want = oracle.csr_apply(ip - ip[0], idx, w, data, mask, (1, 1, nx))[0, 0]
         got = grid[iz, iy].cpu().numpy()
         np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
-        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5 * scale, equal_nan=True)
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=ATOL_FRAC * scale, equal_nan=True)
         pairs += int(ip[-1] - ip[0])
     assert np.isfinite(grid[plane, ny // 2, nx // 2].item())          # the radar's own column is filled
     assert pairs > 500_000

@@ -4,7 +4,8 @@
  * the CPU oracle on the same seeded inputs,
 
 at sizes the oracle finishes in seconds.  Bars: neighbour sets / indices bit-exact; Barnes weights within 1
-float32 ulp; gridded values rtol 1e-5 with an absolute floor of 1e-5 * max|field| (both sides sum float32 products in
+float32 ulp; gridded values rtol 1e-5 with an absolute floor of 2e-6 * max|field| (conftest.ATOL_FRAC: three times the
+largest absolute error ever measured; both sides sum float32 products in
 float32 but in different orders -- NumPy's reduceat vs the kernel's tile/lane order -- so a weighted mean of mixed-sign
 data that cancels to nearly zero has no relative floor; test_reference_grid_relative_error measures how often the floor
 is needed and asserts the pure relative bar wherever |want| > 1e-3 * max|field|); products bit-exact.
@@ -12,7 +13,7 @@ is needed and asserts the pure relative bar wherever |want| > 1e-3 * max|field|)
 import numpy as np
 import pytest
 
-from conftest import (builder_kwargs, golden_names, grid_spec, load_golden, reference_indices, volume_for)
+from conftest import (ATOL_FRAC, builder_kwargs, golden_names, grid_spec, load_golden, reference_indices, volume_for)
 from oracle import radar_grid_oracle as oracle
 
 pytestmark = pytest.mark.gpu
@@ -28,8 +29,9 @@ def rg():
 
 
 def _atol(data, mask):
+    """The absolute floor: ATOL_FRAC (2e-6, conftest.py) * max|field| over the unmasked finite gates."""
     good = np.isfinite(data) & ~mask
-    return RTOL * float(np.abs(data[good]).max()) if good.any() else 0.0
+    return ATOL_FRAC * float(np.abs(data[good]).max()) if good.any() else 0.0
 
 
 def _assert_grid_close(got, want, atol):
@@ -207,7 +209,7 @@ def test_compact_kernel_matches_reference(rg, name):
 
 def test_reference_grid_relative_error(rg):
     """north_star's bar is "<= 1e-5 relative fp32".  Both sides multiply and sum in float32 but in different orders, so
-    the comparison above carries an absolute floor (1e-5 * max|field|) for weighted means that cancel to ~0.  This test
+    the comparison above carries an absolute floor (2e-6 * max|field|) for weighted means that cancel to ~0.  This test
     justifies it: over every reference fixture grid, per field, it measures the worst RELATIVE error on the voxels whose
     magnitude is above 1e-3 * max|field| and asserts <= 1e-5 there with NO absolute term, and it counts the voxels of
     the whole grid that only pass thanks to the floor -- for the standard kernel (``apply_geometry`` on these small
@@ -239,7 +241,7 @@ def test_reference_grid_relative_error(rg):
                 assert gridder.packed_stream
             for fname in meta["fields"]:
                 data, mask = oracle.merge_masks(vol.fields[fname])
-                scale = _atol(data, mask) / RTOL                    # max |field| over the unmasked finite gates
+                scale = _atol(data, mask) / ATOL_FRAC               # max |field| over the unmasked finite gates
                 if gridder is None:
                     got = rg.apply_geometry(geom, rg.get_field_data(radar, fname))
                 else:

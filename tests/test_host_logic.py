@@ -262,7 +262,7 @@ class TestNativeLibrary:
 
     def test_version_and_constants(self):
         lib = rg.load_library(require_device=False)
-        assert lib.rg_version() == 100
+        assert lib.rg_version() == _native.ABI_VERSION == 102
         header = open(os.path.join(REPO, "include", "radargrid_hip.h")).read()
         assert f"0x{_native.RG_EXCLUDED_BITS:08X}" in header.upper().replace("0X", "0x")
         assert np.isnan(np.array([_native.RG_EXCLUDED_BITS], dtype=np.uint32).view(np.float32)[0])
@@ -282,6 +282,83 @@ class TestNativeLibrary:
         assert lib.rg_gate_mask_f32(1 << 12, 8, 99, 0.0, 0.0, 1 << 12, None) == _native.RG_EINVAL
         assert lib.rg_geom_bin_workspace_bytes(-1, 4, 4) == _native.RG_EINVAL
         assert lib.rg_geom_bin_workspace_bytes(1000, 4, 4) > 4 * 1000 * 4
+
+    def test_product_library_refuses_experiment_codes(self):
+        """Timing-only kernels (results wrong by construction) and tuning variants are not in the shipped library: their
+        tile / variant codes are RG_EINVAL (validation only, nothing is launched), and no DIAG instantiation of the row-wise
+        kernel is linked in (VERDICT r3 #6)."""
+        import subprocess
+        lib = rg.load_library(require_device=False)
+        p = 1 << 12                                   # never dereferenced: every call fails validation first
+        for tile in (2100, 2102, 2116, 2199, 2201, 2264, 2265, 1999, 385):
+            st = lib.rg_csr_compact_apply_packed_f32(p, 0, p, p, _native.RG_REC_ORDER_DISPATCH, 120 << 23, p, p, 64, 0, 64, 1,
+                                                     p, 1, 1, 64, 0.0, p, 256, tile, None)
+            assert st == _native.RG_EINVAL, (tile, st)
+        for tile in (901, 903, 909, 5384, 1000):
+            st = lib.rg_csr_compact_apply_f32(p, 0, p, p, p, p, 64, 0, 64, 1, p, 1, 1, 64, 0.0, p, 256, tile, None)
+            assert st == _native.RG_EINVAL, (tile, st)
+        for variant in (8, 9, 16, 19, 22, 28, 640):
+            st = lib.rg_csr_apply_f32_ex(p, 0, p, p, 64, 0, 64, p, 1, 1, 64, 0.0, p, variant, None)
+            assert st == _native.RG_EINVAL, (variant, st)
+        import shutil
+        nm_exe = shutil.which("nm")
+        assert nm_exe, "binutils nm is part of the image"
+        nm = subprocess.run([nm_exe, "-C", "--defined-only", _native.LIB_PATH], capture_output=True, text=True)
+        if nm.returncode == 0:       # host-side kernel stubs carry the template arguments
+            rows = [l for l in nm.stdout.splitlines() if "csr_compact_rowwise_kernel<" in l]
+            assert rows, "row-wise kernel not found in the symbol table"
+            for l in rows:           # <IndT, NF, STRIDE, DIAG>: DIAG must be 0 everywhere
+                args = l[l.index("csr_compact_rowwise_kernel<") + len("csr_compact_rowwise_kernel<"):].split(">(")[0].split(",")
+                assert args[-1].strip() == "0", l
+
+    def test_ensure_built_rebuilds_a_stale_library(self, tmp_path, monkeypatch):
+        """ensure_built() compiles when the library is missing AND when it was built from other sources or headers than
+        the tree holds (content digest in the .stamp file next to it) -- and leaves an up-to-date library alone."""
+        from radar_processor_amd import build as rg_build
+        src, hdr = tmp_path / "k.hip", tmp_path / "k.hpp"
+        src.write_text("// kernel\n")
+        hdr.write_text("// header v1\n")
+        lib = tmp_path / "lib.so"
+        calls = []
+
+        def fake_build(force=False, verbose=True):
+            calls.append(force)
+            lib.write_text("built")
+            (tmp_path / "lib.so.stamp").write_text(rg_build.source_digest() + "\n")
+            return str(lib)
+        monkeypatch.setattr(rg_build, "sources_and_headers", lambda: [str(src), str(hdr)])
+        monkeypatch.setattr(rg_build, "LIB_PATH", str(lib))
+        monkeypatch.setattr(rg_build, "STAMP_PATH", str(lib) + ".stamp")
+        monkeypatch.setattr(rg_build, "CSRC", str(tmp_path))
+        monkeypatch.setattr(rg_build, "build", fake_build)
+        assert rg_build.is_stale()
+        rg_build.ensure_built(verbose=False)
+        assert calls == [False] and not rg_build.is_stale()
+        rg_build.ensure_built(verbose=False)                      # up to date: nothing happens
+        assert calls == [False]
+        os.utime(hdr, (1, 1))                                     # time stamps alone do not matter (snapshots reorder them)
+        assert not rg_build.is_stale()
+        hdr.write_text("// header v2: a signature changed\n")    # a header edit does
+        assert rg_build.is_stale()
+        rg_build.ensure_built(verbose=False)
+        assert calls == [False, True] and not rg_build.is_stale()
+        (tmp_path / "lib.so.stamp").unlink()                      # a library of unknown provenance is rebuilt too
+        assert rg_build.is_stale()
+
+    def test_the_in_tree_library_matches_its_sources(self):
+        from radar_processor_amd import build as rg_build
+        assert not rg_build.is_stale(), "libradargrid_hip.so was built from other sources: python -m radar_processor_amd.build"
+
+    def test_loader_refuses_a_library_of_another_abi_version(self, monkeypatch):
+        """A stale library whose signatures differ must not be called with shifted arguments (ADVICE r3): the loader
+        compares rg_version() with the version this binding was written for."""
+        monkeypatch.setattr(_native, "_lib", None)
+        monkeypatch.setattr(_native, "ABI_VERSION", _native.ABI_VERSION + 1)
+        with pytest.raises(rg.NativeUnavailable, match="header version"):
+            _native.load_library(require_device=False)
+        monkeypatch.undo()
+        assert _native.load_library(require_device=False).rg_version() == _native.ABI_VERSION
+        assert "RG_LIBRARY" not in open(_native.__file__).read().replace("no environment override", "")
 
     @pytest.mark.skipif(not _no_gpu(), reason="only meaningful on a box without a GPU")
     def test_no_cpu_fallback(self, geometry):

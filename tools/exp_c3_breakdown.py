@@ -10,6 +10,9 @@ import tempfile
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import build_experiments            # the timing-only tile codes exist only in the -DRG_EXPERIMENTS build
+build_experiments.use()
 
 
 def main():

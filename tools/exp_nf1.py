@@ -5,6 +5,9 @@ arrays -- the timing-only ablations of the tile kernel (tile codes 902-909: no r
 import json, os, sys, tempfile
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import build_experiments            # the timing-only tile codes exist only in the -DRG_EXPERIMENTS build
+build_experiments.use()
 import torch
 import radar_processor_amd as rg
 from radar_processor_amd import synthetic

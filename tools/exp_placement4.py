@@ -12,6 +12,9 @@ import tempfile
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import build_experiments            # the timing-only tile codes exist only in the -DRG_EXPERIMENTS build
+build_experiments.use()
 
 VARIANTS = [("shipped", 0), ("no_window_gather", 2101), ("no_store", 2102), ("no_gather_no_store", 2103),
             ("rec_sc0", 2104), ("rec_nt", 2108), ("no_rec_loads", 2116), ("no_rec_no_gather", 2117),

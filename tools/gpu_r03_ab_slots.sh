@@ -10,7 +10,7 @@ python3 -m radar_processor_amd.build > gpurun_out/${TAG}_build.log 2>&1 || exit 
 C=radar_processor_amd/csrc
 build_variant() {   # name, flags...
   local name=$1; shift
-  hipcc -std=c++17 -O3 --offload-arch=gfx950 -fPIC -Iinclude -I$C -ffp-contract=off "$@" -c $C/rg_csr_compact.hip -o /tmp/${TAG}_$name.o &&
+  hipcc -std=c++17 -O3 --offload-arch=gfx950 -fPIC -Iinclude -I$C -ffp-contract=off -DRG_EXPERIMENTS "$@" -c $C/rg_csr_compact.hip -o /tmp/${TAG}_$name.o &&
   hipcc --offload-arch=gfx950 -shared -fPIC $C/rg_core.o $C/rg_csr_apply.o /tmp/${TAG}_$name.o $C/rg_products.o $C/rg_geometry.o $C/rg_roi_grid.o $C/rg_raster.o -o /tmp/${TAG}_lib$name.so
 }
 FIELDS=1,2,3,4
