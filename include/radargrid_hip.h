@@ -387,6 +387,43 @@ int rg_csr_compact_apply_packed_f32(const void* indptr, int32_t indptr_is_i64, c
                                     int64_t n_gates, float fill_value, float* out, int32_t window_cap, int32_t tile,
                                     rg_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * K1p  the row-wise kernel with workgroups PERSISTENT over a column of chunks, and an optional products epilogue.
+ * Replaces, in one pass over the packed records: radar_grid/interpolate.py:69-104 (apply_geometry) / :137-140
+ * (apply_geometry_multi) and -- when the caller keeps 2-D products only -- the read-back of the 3-D grid by
+ * radar_grid/products.py:462-490 (column_max over a level window) and :361-412 (CAPPI: the two bracketing levels).
+ * A workgroup walks the chunks (plane z, line group yg, segment sx) of ONE (yg, sx) through the planes of its level piece:
+ * four wavefronts stream the records exactly as rg_csr_compact_apply_packed_f32 (tile = 0) does, a fifth gathers the NEXT
+ * chunk's field window into a second LDS window and publishes the chunk after that one's row pointers, so the per-chunk
+ * chain of dependent loads leaves the critical path and the record stream runs on across chunk boundaries.
+ * Arguments up to fill_value: as rg_csr_compact_apply_packed_f32 (either record order is accepted).
+ *   out           [n_fields][n_vox] 3-D grids, or NULL: the grids are not stored (products only);
+ *   level_planes  [n_fields][n_keep][ny*nx] or NULL: planes keep_lo .. keep_lo + n_keep - 1 of every field's grid (what a
+ *                 CAPPI blends with rg_cappi_lerp_f32, products.py:406-412, or returns as is, :378,386);
+ *   col_max / col_arg  [n_fields][ny*nx] or NULL: NaN-ignoring maximum over planes col_lo .. col_hi and the first plane
+ *                 attaining it (-1: all NaN) -- the contract of rg_column_reduce_f32(RG_COL_MAX), bit for bit, because lane
+ *                 == (y, x) column sees its levels in ascending order;
+ *   z_pieces      1 .. planes: a column is cut into this many level ranges, one workgroup each (more workgroups for
+ *                 small grids; any value gives the same results).  With col_max and z_pieces > 1 the partial planes live
+ *                 in `workspace` (rg_csr_columns_workspace_bytes) and are merged in ascending level order by a second
+ *                 small kernel on the same stream;
+ *   order         NULL, or a permutation of 0 .. z_pieces * ceil(ny / RG_COMPACT_LINES) * ceil(nx / 64) - 1: workgroup b
+ *                 takes item order[b] = piece * columns + (yg * ceil(nx / 64) + c) -- the caller may list the heaviest
+ *                 columns first (speed only);
+ *   lanes_hint    0, or the diagnostic lane split of the row-wise kernel (1 .. 64 lanes per row, 70 + t).
+ * The grids are the same BITS as rg_csr_compact_apply_packed_f32 (tile = 0) for the same lanes_hint (same order of the
+ * float32 adds: geometry and field count alone fix it).  At least one of out / level_planes / col_max must be given.
+ * ------------------------------------------------------------------------------------------------- */
+int64_t rg_csr_columns_workspace_bytes(int64_t lines_per_plane, int64_t line_len, int32_t n_fields, int32_t z_pieces);
+int rg_csr_compact_apply_columns_f32(const void* indptr, int32_t indptr_is_i64, const void* records,
+                                     const int64_t* rec_ptr, int32_t rec_order, uint32_t w_base, const int64_t* dict_ptr,
+                                     const int32_t* dict, int64_t n_vox, int64_t n_pairs, int64_t line_len,
+                                     int64_t lines_per_plane, const float* packed, int32_t n_fields, int32_t stride,
+                                     int64_t n_gates, float fill_value, float* out, float* level_planes, int32_t keep_lo,
+                                     int32_t n_keep, float* col_max, int32_t* col_arg, int32_t col_lo, int32_t col_hi,
+                                     int32_t window_cap, int32_t z_pieces, const int32_t* order, void* workspace,
+                                     int64_t workspace_bytes, int32_t lanes_hint, rg_stream_t stream);
+
 /* number of chunks of a grid of n_rows rows (negative rg_status when the sizes do not factor) */
 int64_t rg_csr_compact_chunks(int64_t n_rows, int64_t line_len, int64_t lines_per_plane);
 

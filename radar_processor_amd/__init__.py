@@ -20,7 +20,7 @@ from .grid_products import (EARTH_RADIUS, EFFECTIVE_RADIUS_FACTOR, column_argmax
                             column_min, compute_beam_height, compute_beam_height_flat, compute_beam_height_simple,
                             constant_altitude_ppi, constant_elevation_ppi, get_beam_height_difference,
                             get_elevation_from_z_level)
-from .gridding import apply_geometry, apply_geometry_multi, grid_fields_device
+from .gridding import PlaneProducts, apply_geometry, apply_geometry_multi, grid_fields_device, grid_products_device
 from .roi_grid import roi_grid_fields_device
 from .processor_seam import build_grid3d_package
 from .raster import (PlaneTest, apply_colormap_to_array, apply_filter_masks, collapse_field_3d_to_2d,
@@ -44,7 +44,7 @@ __all__ = [
     # 2-D raster stage of radar_processor (utils.py:336-387, processor.py:480-551, :802-886)
     "collapse_field_3d_to_2d", "collapse_grid_to_2d", "apply_filter_masks",
     # build-specific additions
-    "column_argmax", "grid_fields_device", "roi_grid_fields_device", "build_grid3d_package", "device_gate_mask", "RoiSearch", "DeviceCSR",
+    "column_argmax", "grid_fields_device", "grid_products_device", "PlaneProducts", "roi_grid_fields_device", "build_grid3d_package", "device_gate_mask", "RoiSearch", "DeviceCSR",
     "collapse_plane_device", "plane_filter_device", "PlaneTest", "colormap_lut", "colormap_rgba_device",
     "NativeUnavailable", "NativeError", "load_library",
 ]

@@ -86,6 +86,12 @@ SIGNATURES = {
     "rg_csr_compact_apply_packed_f32": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, ctypes.c_uint32, c_void_p,
                                                   c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int32,
                                                   c_int32, c_int64, c_float, c_void_p, c_int32, c_int32, c_void_p]),
+    "rg_csr_columns_workspace_bytes": (c_int64, [c_int64, c_int64, c_int32, c_int32]),
+    "rg_csr_compact_apply_columns_f32": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, ctypes.c_uint32, c_void_p,
+                                                   c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int32,
+                                                   c_int32, c_int64, c_float, c_void_p, c_void_p, c_int32, c_int32,
+                                                   c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
+                                                   c_void_p, c_int64, c_int32, c_void_p]),
     "rg_csr_compact_chunks": (c_int64, [c_int64, c_int64, c_int64]),
     "rg_csr_compact_count": (c_int32, [c_void_p, c_int32, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p,
                                        c_void_p]),

@@ -185,13 +185,38 @@ class VolumeBatch:
     def grid_shard(self, volumes: Sequence[dict], products: Optional[Callable] = None, rank=None,
                    world_size=None, events: Optional[list] = None) -> Dict[int, object]:
         """Returns ``{volume index: grids [F, nz, ny, nx]}`` -- or ``{index: products(grids)}`` when a reducer is
-        given, so that only 2-D planes outlive the pass.  ``volumes`` is indexed by the GLOBAL volume number; only this
+        given, so that only 2-D planes outlive the pass.  ``products`` may also be a :class:`gridding.PlaneProducts`
+        (column maximum / argmax / CAPPIs): the result is then ``{index: [one dict of planes per field]}`` and, on the CSR
+        path of a large geometry, the pass runs the column-persistent kernel with its products epilogue -- the 3-D grids
+        are neither written nor read back (``gridding.grid_products_device``).  ``volumes`` is indexed by the GLOBAL volume number; only this
         rank's entries (``shard_indices``) are touched, the others may be ``None``.  ``events``: optional list that
         receives one ``(start, end)`` pair of stream events per gridding pass (mask fold + gridding kernel), for
         callers that time the kernel itself (``bench.py``)."""
         import torch
-        from .gridding import grid_fields_device
+        from .gridding import PlaneProducts, grid_fields_device, grid_products_device
         from .roi_grid import roi_grid_fields_device
+        plane_spec = products if isinstance(products, PlaneProducts) else None
+        if plane_spec is not None and self.fused:      # the CSR-free gridder has no epilogue: reduce its grids as usual
+            from . import grid_products as gp
+            geom_like = self.geometry
+
+            def products(g, _spec=plane_spec):         # noqa: F811 -- the reducer form of the same request
+                recs = []
+                for k in range(g.shape[0]):
+                    rec = {}
+                    lo, hi = gp._level_window(int(g.shape[1]), *_spec.window, geom_like)
+                    if _spec.colmax:
+                        got = gp._column("max", g[k], lo, hi, None, None, None, want_arg=_spec.argmax)
+                        if _spec.argmax:
+                            rec["colmax"], rec["argmax"] = got
+                        else:
+                            rec["colmax"] = got
+                    if _spec.cappi:
+                        rec["cappi"] = {alt: gp.constant_altitude_ppi(g[k], geom_like, alt, _spec.interpolation)
+                                        for alt in _spec.cappi}
+                    recs.append(rec)
+                return recs
+            plane_spec = None
         mine = shard_indices(len(volumes), rank, world_size)
         out: Dict[int, object] = {}
         n_f = len(self.field_names)
@@ -212,8 +237,11 @@ class VolumeBatch:
             if events is not None:
                 pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 pair[0].record()
+            planes = None
             if self.fused:
                 grids = roi_grid_fields_device(self.geometry, fields, masks, weighting=self.weighting)
+            elif plane_spec is not None:                # products only: one fused launch per group, no 3-D grid in HBM
+                planes = grid_products_device(self.geometry, fields, masks, products=plane_spec)
             else:
                 grids = grid_fields_device(self.geometry, fields, masks)
             if events is not None:
@@ -222,6 +250,9 @@ class VolumeBatch:
             if ready is not None:                       # this group's staging set may be overwritten once the pass is done
                 self._staging_free[gi & 1] = compute.record_event()
             for i, b in enumerate(group):
+                if planes is not None:
+                    out[b] = planes[i * n_f:(i + 1) * n_f]
+                    continue
                 g = grids[i * n_f:(i + 1) * n_f]
                 out[b] = products(g) if products is not None else g
         return out

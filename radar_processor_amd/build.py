@@ -24,6 +24,7 @@ SOURCES = [
     ("rg_core.hip", []),
     ("rg_csr_apply.hip", []),
     ("rg_csr_compact.hip", []),
+    ("rg_csr_columns.hip", []),
     ("rg_products.hip", []),
     ("rg_geometry.hip", []),
     ("rg_roi_grid.hip", []),

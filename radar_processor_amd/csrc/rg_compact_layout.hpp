@@ -1,0 +1,140 @@
+// Layout of the compact CSR copy shared by the K1c kernels (rg_csr_compact.hip: tile and row-wise kernels;
+// rg_csr_columns.hip: the column-persistent row-wise kernel): chunk grid, block -> chunk rotation, segments, buffer
+// resources, per-field-count tuning of the row-wise kernels.  Everything here has internal linkage on purpose (each
+// translation unit gets its own copy; nothing is exported).
+#pragma once
+
+#include <type_traits>
+
+#include "rg_common.hpp"
+#include "rg_row_phase.hpp"
+
+// 16-byte buffer load by intrinsic name (this compiler's __builtin_amdgcn_raw_buffer_load_b128 returns the first dword
+// in every element, see rg_csr_apply.hip); namespace scope: a name bound to an intrinsic must not have internal linkage.
+using rg_u32x4 = unsigned __attribute__((ext_vector_type(4)));
+__device__ rg_u32x4 rg_buffer_load_v4u32(__amdgpu_buffer_rsrc_t, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.raw.ptr.buffer.load.v4i32");
+
+// v_mul_legacy_f32 by intrinsic name (this clang has no __builtin_amdgcn_fmul_legacy): 0 * x = +0 for EVERY x, NaN and
+// infinity included; any other product is the IEEE one.
+__device__ float rg_fmul_legacy(float, float) __asm("llvm.amdgcn.fmul.legacy");
+
+namespace {
+
+using rg::f32x2;
+using rg::f32x4;
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+constexpr int kRsrcRaw32 = 0x00020000;   // gfx9 buffer resource word 3: DATA_FORMAT = 32, untyped access
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, long bytes) {   // `base` and `bytes` wave-uniform
+  const unsigned nb = bytes >= 0xFFFFFFFFL ? 0xFFFFFFFFu : bytes <= 0 ? 0u : (unsigned)bytes;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)nb, kRsrcRaw32);
+}
+
+constexpr int kH = RG_COMPACT_LINES;   // grid lines (= wavefronts) per chunk
+
+// Where a chunk's wavefronts find their rows: the grid as planes x lines x rows (nz x ny x nx for a radar grid).
+// Chunk arithmetic is 32-bit on purpose: every wavefront decodes its chunk number with two divisions, and a 64-bit
+// division costs this ISA a few hundred instructions (measured: 7 % of the single-field kernel).
+struct ChunkGrid {
+  long line_len;            // rows per line (nx)
+  long lines_per_plane;     // lines per plane (ny)
+  long n_planes;            // planes (nz)
+  unsigned nsx;             // segments per line = ceil(line_len / 64)
+  unsigned nyg;             // line groups per plane = ceil(lines_per_plane / H)
+  unsigned rot_step;        // columns the block -> chunk map rotates per line group (speed only)
+  unsigned seg_base;        // a line's nsx segments are balanced: the first seg_extra hold seg_base + 1 rows, the
+  unsigned seg_extra;       // others seg_base (<= 64 either way) -- rg_csr_apply_f32 cuts its lines the same way
+  unsigned grp0;            // line groups in front of this grid when it is a slab of whole planes of a larger one
+                            // (rg_csr_compact_pack's plane0 * nyg; 0 for the apply kernels): the rotation counts them
+};
+
+// Workgroups are dealt to the 8 XCDs round-robin by blockIdx.  With nsx segments per line a multiple of 8, chunk column
+// sx would always land on XCD sx % 8 and each XCD would own one x-slab of the grid for the whole launch; rotating the
+// columns by rot_step per line group makes every XCD see every column.  The chunk a workgroup takes is a bijection of
+// blockIdx; with RG_REC_ORDER_DISPATCH the records are STORED in this order (see rg_csr_compact_pack), so the map is part
+// of the layout: grid_geometry.CompactCSR.slot_of_segments restates it.
+__device__ __forceinline__ unsigned block_chunk(const ChunkGrid& g, unsigned bid) {
+  const unsigned grp = bid / g.nsx;
+  const unsigned col = bid - grp * g.nsx;
+  const unsigned rot = col + ((grp + g.grp0) * g.rot_step) % g.nsx;
+  return grp * g.nsx + (rot >= g.nsx ? rot - g.nsx : rot);
+}
+
+__host__ __device__ inline long chunk_count(const ChunkGrid& g) { return g.n_planes * (long)g.nyg * (long)g.nsx; }
+
+struct Segment {
+  long r0;      // first row
+  long seg;     // segment number, line-major: (plane * lines_per_plane + line) * nsx + sx
+  int nrows;    // 0 for a wavefront past the last line of the plane
+};
+
+__device__ __forceinline__ Segment chunk_segment(const ChunkGrid& g, unsigned chunk, int w) {   // chunk < 2^31
+  const unsigned grp = chunk / g.nsx;         // line group, counted through all planes
+  const unsigned sx = chunk - grp * g.nsx;
+  const unsigned plane = grp / g.nyg;
+  const unsigned yg = grp - plane * g.nyg;
+  const long y = (long)yg * kH + w;
+  Segment s;
+  if (y >= g.lines_per_plane) {
+    s.r0 = 0;
+    s.seg = 0;
+    s.nrows = 0;
+    return s;
+  }
+  s.seg = ((long)plane * g.lines_per_plane + y) * g.nsx + sx;
+  const unsigned x0 = sx * g.seg_base + (sx < g.seg_extra ? sx : g.seg_extra);
+  s.r0 = ((long)plane * g.lines_per_plane + y) * g.line_len + (long)x0;
+  s.nrows = (int)(g.seg_base + (sx < g.seg_extra ? 1u : 0u));
+  return s;
+}
+
+
+constexpr int stride_for(int nf) { return nf == 1 ? 1 : nf == 2 ? 2 : nf <= 4 ? 4 : 8; }
+
+bool make_chunk_grid(int64_t n_rows, int64_t line_len, int64_t lines_per_plane, ChunkGrid* cg) {
+  if (line_len <= 0) line_len = n_rows > 0 ? n_rows : 1;
+  if (n_rows % line_len != 0) return false;
+  const long n_lines = n_rows / line_len;
+  if (lines_per_plane <= 0) lines_per_plane = n_lines > 0 ? n_lines : 1;
+  if (n_lines % lines_per_plane != 0) return false;
+  cg->line_len = line_len;
+  cg->lines_per_plane = lines_per_plane;
+  cg->n_planes = n_lines / lines_per_plane;
+  const long nsx = (line_len + 63) / 64, nyg = (lines_per_plane + kH - 1) / kH;
+  if (nsx > 0x7FFFFFFFL || nyg > 0x7FFFFFFFL) return false;
+  cg->nsx = (unsigned)nsx;
+  cg->nyg = (unsigned)nyg;
+  cg->seg_base = (unsigned)(line_len / nsx);
+  cg->seg_extra = (unsigned)(line_len % nsx);
+  // measured on the bench grid (32 columns), ms per launch: 0 -> 14.2 (every XCD keeps its columns), 8 -> 10.5,
+  // 1 -> 9.35, 2 -> 9.27, 3 -> 9.24, 5 -> 9.23, 7 -> 9.21, 9 -> 9.22, 11 -> 9.31, 17 -> 9.22
+  cg->rot_step = RG_COMPACT_ROTATION;
+  cg->grp0 = 0;
+  return true;
+}
+
+
+// ---- per-field-count configuration of the row-wise kernels (see rg_csr_compact.hip for what the knobs mean) ----
+template <int NF> struct RowwiseConfig;
+template <> struct RowwiseConfig<1> { static constexpr int kpre = 3, target = 4; static constexpr bool narrow = false, regs = false; };
+template <> struct RowwiseConfig<2> { static constexpr int kpre = 3, target = 4; static constexpr bool narrow = false, regs = false; };
+// Tuning knobs of three fields: fixed in the product library; -DRG_EXPERIMENTS builds (tools/build_experiments.py) may
+// override them with -DRG_ROWWISE_KPRE3=.. etc. for A/B measurements.
+#if !defined(RG_EXPERIMENTS) || !defined(RG_ROWWISE_KPRE3)
+#undef RG_ROWWISE_KPRE3
+#define RG_ROWWISE_KPRE3 3
+#endif
+#if !defined(RG_EXPERIMENTS) || !defined(RG_ROWWISE_TARGET3)
+#undef RG_ROWWISE_TARGET3
+#define RG_ROWWISE_TARGET3 6
+#endif
+#if !defined(RG_EXPERIMENTS) || !defined(RG_ROWWISE_REGS3)
+#undef RG_ROWWISE_REGS3
+#define RG_ROWWISE_REGS3 true
+#endif
+template <> struct RowwiseConfig<3> { static constexpr int kpre = RG_ROWWISE_KPRE3, target = RG_ROWWISE_TARGET3; static constexpr bool narrow = true, regs = RG_ROWWISE_REGS3; };
+template <> struct RowwiseConfig<4> { static constexpr int kpre = 3, target = 8; static constexpr bool narrow = false, regs = true; };
+
+
+}  // namespace

@@ -30,90 +30,9 @@
 //
 // Roofline: HBM.  Bytes per launch = 6*P + 4*D + sizeof(indptr)*(V+1) + 8*(C+1) + F*(5*G + 4*V)  with D = total
 // dictionary entries, C = chunks; with the packed records (see rg_csr_compact_pack) 16*R + 8*(S+1) replace 6*P.
-#include <type_traits>
-
-#include "rg_common.hpp"
-#include "rg_row_phase.hpp"
-
-// 16-byte buffer load by intrinsic name (this compiler's __builtin_amdgcn_raw_buffer_load_b128 returns the first dword
-// in every element, see rg_csr_apply.hip); namespace scope: a name bound to an intrinsic must not have internal linkage.
-using rg_u32x4 = unsigned __attribute__((ext_vector_type(4)));
-__device__ rg_u32x4 rg_buffer_load_v4u32(__amdgpu_buffer_rsrc_t, int voffset, int soffset, int aux)
-    __asm("llvm.amdgcn.raw.ptr.buffer.load.v4i32");
-
-// v_mul_legacy_f32 by intrinsic name (this clang has no __builtin_amdgcn_fmul_legacy): 0 * x = +0 for EVERY x, NaN and
-// infinity included; any other product is the IEEE one.
-__device__ float rg_fmul_legacy(float, float) __asm("llvm.amdgcn.fmul.legacy");
+#include "rg_compact_layout.hpp"
 
 namespace {
-
-using rg::f32x2;
-using rg::f32x4;
-using rsrc_t = __amdgpu_buffer_rsrc_t;
-constexpr int kRsrcRaw32 = 0x00020000;   // gfx9 buffer resource word 3: DATA_FORMAT = 32, untyped access
-
-__device__ __forceinline__ rsrc_t make_rsrc(const void* base, long bytes) {   // `base` and `bytes` wave-uniform
-  const unsigned nb = bytes >= 0xFFFFFFFFL ? 0xFFFFFFFFu : bytes <= 0 ? 0u : (unsigned)bytes;
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)nb, kRsrcRaw32);
-}
-
-constexpr int kH = RG_COMPACT_LINES;   // grid lines (= wavefronts) per chunk
-
-// Where a chunk's wavefronts find their rows: the grid as planes x lines x rows (nz x ny x nx for a radar grid).
-// Chunk arithmetic is 32-bit on purpose: every wavefront decodes its chunk number with two divisions, and a 64-bit
-// division costs this ISA a few hundred instructions (measured: 7 % of the single-field kernel).
-struct ChunkGrid {
-  long line_len;            // rows per line (nx)
-  long lines_per_plane;     // lines per plane (ny)
-  long n_planes;            // planes (nz)
-  unsigned nsx;             // segments per line = ceil(line_len / 64)
-  unsigned nyg;             // line groups per plane = ceil(lines_per_plane / H)
-  unsigned rot_step;        // columns the block -> chunk map rotates per line group (speed only)
-  unsigned seg_base;        // a line's nsx segments are balanced: the first seg_extra hold seg_base + 1 rows, the
-  unsigned seg_extra;       // others seg_base (<= 64 either way) -- rg_csr_apply_f32 cuts its lines the same way
-  unsigned grp0;            // line groups in front of this grid when it is a slab of whole planes of a larger one
-                            // (rg_csr_compact_pack's plane0 * nyg; 0 for the apply kernels): the rotation counts them
-};
-
-// Workgroups are dealt to the 8 XCDs round-robin by blockIdx.  With nsx segments per line a multiple of 8, chunk column
-// sx would always land on XCD sx % 8 and each XCD would own one x-slab of the grid for the whole launch; rotating the
-// columns by rot_step per line group makes every XCD see every column.  The chunk a workgroup takes is a bijection of
-// blockIdx; with RG_REC_ORDER_DISPATCH the records are STORED in this order (see rg_csr_compact_pack), so the map is part
-// of the layout: grid_geometry.CompactCSR.slot_of_segments restates it.
-__device__ __forceinline__ unsigned block_chunk(const ChunkGrid& g, unsigned bid) {
-  const unsigned grp = bid / g.nsx;
-  const unsigned col = bid - grp * g.nsx;
-  const unsigned rot = col + ((grp + g.grp0) * g.rot_step) % g.nsx;
-  return grp * g.nsx + (rot >= g.nsx ? rot - g.nsx : rot);
-}
-
-__host__ __device__ inline long chunk_count(const ChunkGrid& g) { return g.n_planes * (long)g.nyg * (long)g.nsx; }
-
-struct Segment {
-  long r0;      // first row
-  long seg;     // segment number, line-major: (plane * lines_per_plane + line) * nsx + sx
-  int nrows;    // 0 for a wavefront past the last line of the plane
-};
-
-__device__ __forceinline__ Segment chunk_segment(const ChunkGrid& g, unsigned chunk, int w) {   // chunk < 2^31
-  const unsigned grp = chunk / g.nsx;         // line group, counted through all planes
-  const unsigned sx = chunk - grp * g.nsx;
-  const unsigned plane = grp / g.nyg;
-  const unsigned yg = grp - plane * g.nyg;
-  const long y = (long)yg * kH + w;
-  Segment s;
-  if (y >= g.lines_per_plane) {
-    s.r0 = 0;
-    s.seg = 0;
-    s.nrows = 0;
-    return s;
-  }
-  s.seg = ((long)plane * g.lines_per_plane + y) * g.nsx + sx;
-  const unsigned x0 = sx * g.seg_base + (sx < g.seg_extra ? sx : g.seg_extra);
-  s.r0 = ((long)plane * g.lines_per_plane + y) * g.line_len + (long)x0;
-  s.nrows = (int)(g.seg_base + (sx < g.seg_extra ? 1u : 0u));
-  return s;
-}
 
 // ABLATE (timing-only diagnostics, results wrong by construction): 1 = no row phase, 2 = no products and no row phase
 // (the values still have to be looked up: they are summed into the output), 3 = neither products, row phase nor window
@@ -331,7 +250,6 @@ __global__ __launch_bounds__(64 * kH) void csr_compact_kernel(
   }
 }
 
-constexpr int stride_for(int nf) { return nf == 1 ? 1 : nf == 2 ? 2 : nf <= 4 ? 4 : 8; }
 
 template <typename IndT, int NF, int TILE>
 constexpr size_t static_lds() {
@@ -416,28 +334,6 @@ int launch(int nf, int tile, int window_cap, const void* indptr, const uint16_t*
     default: return RG_K1C(8, 128);
   }
 #undef RG_K1C
-}
-
-bool make_chunk_grid(int64_t n_rows, int64_t line_len, int64_t lines_per_plane, ChunkGrid* cg) {
-  if (line_len <= 0) line_len = n_rows > 0 ? n_rows : 1;
-  if (n_rows % line_len != 0) return false;
-  const long n_lines = n_rows / line_len;
-  if (lines_per_plane <= 0) lines_per_plane = n_lines > 0 ? n_lines : 1;
-  if (n_lines % lines_per_plane != 0) return false;
-  cg->line_len = line_len;
-  cg->lines_per_plane = lines_per_plane;
-  cg->n_planes = n_lines / lines_per_plane;
-  const long nsx = (line_len + 63) / 64, nyg = (lines_per_plane + kH - 1) / kH;
-  if (nsx > 0x7FFFFFFFL || nyg > 0x7FFFFFFFL) return false;
-  cg->nsx = (unsigned)nsx;
-  cg->nyg = (unsigned)nyg;
-  cg->seg_base = (unsigned)(line_len / nsx);
-  cg->seg_extra = (unsigned)(line_len % nsx);
-  // measured on the bench grid (32 columns), ms per launch: 0 -> 14.2 (every XCD keeps its columns), 8 -> 10.5,
-  // 1 -> 9.35, 2 -> 9.27, 3 -> 9.24, 5 -> 9.23, 7 -> 9.21, 9 -> 9.22, 11 -> 9.31, 17 -> 9.22
-  cg->rot_step = RG_COMPACT_ROTATION;
-  cg->grp0 = 0;
-  return true;
 }
 
 }  // namespace
@@ -623,26 +519,6 @@ extern "C" int rg_csr_compact_pack(const void* indptr, int32_t indptr_is_i64, co
 namespace {
 
 constexpr int kRowwiseChunksPerBlock = 1;   // consecutive chunks one workgroup takes (see the kernel: 1 measured best)
-
-template <int NF> struct RowwiseConfig;
-template <> struct RowwiseConfig<1> { static constexpr int kpre = 3, target = 4; static constexpr bool narrow = false, regs = false; };
-template <> struct RowwiseConfig<2> { static constexpr int kpre = 3, target = 4; static constexpr bool narrow = false, regs = false; };
-// Tuning knobs of three fields: fixed in the product library; -DRG_EXPERIMENTS builds (tools/build_experiments.py) may
-// override them with -DRG_ROWWISE_KPRE3=.. etc. for A/B measurements.
-#if !defined(RG_EXPERIMENTS) || !defined(RG_ROWWISE_KPRE3)
-#undef RG_ROWWISE_KPRE3
-#define RG_ROWWISE_KPRE3 3
-#endif
-#if !defined(RG_EXPERIMENTS) || !defined(RG_ROWWISE_TARGET3)
-#undef RG_ROWWISE_TARGET3
-#define RG_ROWWISE_TARGET3 6
-#endif
-#if !defined(RG_EXPERIMENTS) || !defined(RG_ROWWISE_REGS3)
-#undef RG_ROWWISE_REGS3
-#define RG_ROWWISE_REGS3 true
-#endif
-template <> struct RowwiseConfig<3> { static constexpr int kpre = RG_ROWWISE_KPRE3, target = RG_ROWWISE_TARGET3; static constexpr bool narrow = true, regs = RG_ROWWISE_REGS3; };
-template <> struct RowwiseConfig<4> { static constexpr int kpre = 3, target = 8; static constexpr bool narrow = false, regs = true; };
 
 // DIAG (timing-only diagnostics of tools/exp_placement4.py, results wrong by construction; one field only): bit 0 = the
 // window is not gathered (no dictionary / field reads), bit 1 = no output store, bit 2 / bit 3 = cache policy sc0 / nt on

@@ -57,7 +57,7 @@ class CompactCSR:
     above 65536.  ``indptr`` and ``weights`` are shared with the standard CSR."""
 
     __slots__ = ("local_idx", "dict_ptr", "dict", "n_dict", "max_dict", "window_cap", "grid_shape", "chunk_pairs",
-                 "chunk_counts", "rec", "rec_ptr", "rec_order", "w_base", "_pack_tried")
+                 "chunk_counts", "rec", "rec_ptr", "rec_order", "w_base", "_pack_tried", "_column_orders")
 
     def __init__(self, local_idx, dict_ptr, dict_, max_dict: int, window_cap: int, grid_shape, chunk_pairs=None,
                  chunk_counts=None):
@@ -76,6 +76,7 @@ class CompactCSR:
         self.rec_order = DEFAULT_REC_ORDER  # RG_REC_ORDER_SEGMENT (slot = segment) / RG_REC_ORDER_DISPATCH (slot_of_segments)
         self.w_base = 0                     # weight code = float32 bits - w_base
         self._pack_tried = False
+        self._column_orders = {}            # z_pieces -> workgroup order of the column kernel (gridding.CsrGridder)
 
     def nbytes(self) -> int:
         return sum(int(t.numel()) * t.element_size()

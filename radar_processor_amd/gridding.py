@@ -184,6 +184,76 @@ class CsrGridder:
             float(np.float32(fill_value)), _native.ptr(out), self.tile if self.tile in _PIPELINE_TILES else 0,
             _native.stream_ptr()), "rg_csr_apply_f32")
 
+    # ---- column-persistent kernel (rg_csr_compact_apply_columns_f32) ------------------------------------------------
+    @property
+    def has_columns_kernel(self) -> bool:
+        """The column-persistent kernel reads the packed records: 1-4 fields, codable weights."""
+        return self.compact is not None and self.packed_stream
+
+    def _column_plan(self, z_pieces: int):
+        """``(z_pieces, order tensor)`` for this geometry: enough workgroups to fill the chip (a workgroup is one column
+        of chunks, or one of ``z_pieces`` level ranges of it), listed heaviest first -- workgroups are handed out in
+        ``blockIdx`` order as slots free up, so starting the long columns first is what keeps the tail short (greedy
+        longest-processing-time scheduling).  Cached on the compact copy."""
+        torch = _native.torch_mod()
+        c = self.compact
+        nz, ny, nx = self.grid_shape
+        nsx, nyg, _ = c.layout(self.grid_shape)
+        n_cols = nsx * nyg
+        if z_pieces <= 0:
+            z_pieces = max(1, min(nz, -(-_COLUMNS_MIN_WORKGROUPS // max(n_cols, 1))))
+        z_pieces = max(1, min(int(z_pieces), nz))
+        cache = c._column_orders
+        order = cache.get(z_pieces)
+        if order is None:
+            if c.chunk_pairs is not None and c.chunk_pairs.numel() == nz * nyg * nsx:
+                cp = c.chunk_pairs.view(nz, nyg, nsx)
+                yg = torch.arange(nyg, device=cp.device)[:, None]
+                col = torch.arange(nsx, device=cp.device)[None, :]
+                sx = (col + (yg * _native.RG_COMPACT_ROTATION) % nsx) % nsx            # the kernel's column -> segment map
+                parts = []
+                for p in range(z_pieces):
+                    z0, z1 = p * nz // z_pieces, (p + 1) * nz // z_pieces
+                    parts.append(torch.gather(cp[z0:z1].sum(dim=0), 1, sx).reshape(-1))
+                weight = torch.cat(parts)
+                order = torch.argsort(weight, descending=True, stable=True).to(torch.int32)
+            else:
+                order = False                                        # no statistics: identity order
+            cache[z_pieces] = order
+        return z_pieces, (None if order is False else order)
+
+    def apply_columns(self, out=None, fill_value: float = np.nan, level_planes=None, keep_lo: int = 0, col_max=None,
+                      col_arg=None, col_window=None, z_pieces: int = 0, lanes_hint: int = 0, ordered: bool = True) -> None:
+        """One pass of ``rg_csr_compact_apply_columns_f32`` over the packed records (workgroups persistent over a column of
+        chunks, the next chunk's window prefetched): ``out`` ``[F, n_vox]`` receives the same bits as :meth:`apply` with the
+        row-wise kernel, or is ``None`` when only 2-D products are wanted -- ``level_planes`` ``[F, n_keep, ny, nx]``
+        (planes ``keep_lo ..`` of every grid), ``col_max`` / ``col_arg`` ``[F, ny, nx]`` (``column_argmax`` over the level
+        window ``col_window = (lo, hi)``, default all levels)."""
+        torch = _native.torch_mod()
+        if not self.has_columns_kernel:
+            raise _native.NativeError("the column-persistent kernel needs the packed records (1-4 fields, codable weights)")
+        csr, c = self.csr, self.compact
+        nz, ny, nx = self.grid_shape
+        n_keep = 0 if level_planes is None else int(level_planes.shape[1])
+        lo, hi = (0, nz - 1) if col_window is None else (int(col_window[0]), int(col_window[1]))
+        pieces, order = self._column_plan(z_pieces)
+        if not ordered:
+            order = None
+        ws = None
+        if col_max is not None and pieces > 1:
+            nbytes = int(self.lib.rg_csr_columns_workspace_bytes(ny, nx, self.n_fields, pieces))
+            ws = getattr(self, "_columns_ws", None)
+            if ws is None or ws.numel() < nbytes:
+                ws = self._columns_ws = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
+        window = min(self.window, c.window_for(self.n_fields, _COLUMNS_WINDOW_BYTES))
+        _native.check(self.lib.rg_csr_compact_apply_columns_f32(
+            _native.ptr(csr.indptr), int(csr.is_i64), _native.ptr(c.rec), _native.ptr(c.rec_ptr), c.rec_order, c.w_base,
+            _native.ptr(c.dict_ptr), _native.ptr(c.dict), self.n_vox, csr.n_pairs, nx, ny, _native.ptr(self.packed),
+            self.n_fields, self.stride, self.n_gates, float(np.float32(fill_value)), _native.ptr(out),
+            _native.ptr(level_planes), int(keep_lo), n_keep, _native.ptr(col_max), _native.ptr(col_arg), lo, hi, window,
+            pieces, _native.ptr(order), _native.ptr(ws), 0 if ws is None else int(ws.numel()), int(lanes_hint),
+            _native.stream_ptr()), "rg_csr_compact_apply_columns_f32")
+
     def algorithmic_bytes(self) -> int:
         """Bytes one ``apply`` launch must move: index + weight per pair, the row pointers,
         each field's values + mask once, each output grid once."""
@@ -206,6 +276,8 @@ class CsrGridder:
                 + self.n_fields * (5 * self.n_gates + 4 * self.n_vox))
 
 
+_COLUMNS_MIN_WORKGROUPS = 8192      # column kernel: cut columns into level pieces until the launch has about this many workgroups
+_COLUMNS_WINDOW_BYTES = 28672       # ... and each of its TWO LDS windows may take this much (64 KiB per workgroup in all)
 _PIPELINE_TILES = (128, 192, 256, 320, 384, 512)   # pairs per pipeline step the tile kernels accept (0 = their default)
 _COMPACT_MIN_PAIRS = 50_000_000     # below this a pass takes well under a millisecond either way
 _COMPACT_MAX_WINDOW_BYTES = 24576  # LDS window beyond which the standard kernel is the faster one (CsrGridder.__init__)
@@ -297,6 +369,115 @@ def grid_fields_device(geometry: GridGeometry, fields: Sequence, masks: Optional
             gridder.pack(fields[f0:f1], masks[f0:f1], shared_mask)
             gridder.apply(out.view(n_fields, n_vox)[f0:f1], fill_value)
     return out.view(n_fields, nz, ny, nx)
+
+
+class PlaneProducts:
+    """The 2-D products a products-only pass keeps of every gridded field (``grid_products_device``,
+    ``batch.VolumeBatch.grid_shard(products=PlaneProducts(...))``): the column maximum over a level window
+    (``radar_grid/products.py:420-490``; same window arguments as ``column_max``), optionally the level that attains it
+    (``column_argmax``), and CAPPIs at the given altitudes (``products.py:317-415``).  With these and nothing else wanted,
+    the 3-D grid never has to exist in HBM: the column-persistent gridding kernel keeps the running maximum in registers
+    and stores only the levels the CAPPIs blend."""
+
+    def __init__(self, colmax: bool = True, argmax: bool = True, cappi: Sequence[float] = (), interpolation: str = "linear",
+                 z_min_idx: Optional[int] = None, z_max_idx: Optional[int] = None, z_min_alt: Optional[float] = None,
+                 z_max_alt: Optional[float] = None):
+        if interpolation not in ("linear", "nearest"):
+            raise ValueError(f"Unknown interpolation method: {interpolation}")
+        self.colmax = bool(colmax or argmax)
+        self.argmax = bool(argmax)
+        self.cappi = tuple(float(a) for a in cappi)
+        self.interpolation = interpolation
+        self.window = (z_min_idx, z_max_idx, z_min_alt, z_max_alt)
+
+
+def grid_products_device(geometry: GridGeometry, fields: Sequence, masks: Optional[Sequence] = None, shared_mask=None,
+                         products: Optional[PlaneProducts] = None, fill_value: float = np.nan, fused: Optional[bool] = None):
+    """Grid device-resident fields and return ONLY 2-D products: a list with one ``dict`` per field --
+    ``{"colmax": [ny, nx] float32, "argmax": [ny, nx] int32, "cappi": {altitude: [ny, nx] float32}}`` (keys present as
+    requested by ``products``).  The planes are bit-identical to ``column_argmax`` / ``constant_altitude_ppi`` applied to
+    the grid ``grid_fields_device`` returns for the same pass.
+
+    Large geometries (packed records present) run ONE launch of the column-persistent kernel per group of up to four
+    fields with its products epilogue: no 3-D grid is written or read back (640 MB each way per field on the bench grid).
+    Other geometries -- and ``fused=False`` -- grid as usual and reduce with the separate kernels."""
+    from . import grid_products as gp
+    torch = _native.torch_mod()
+    products = products if products is not None else PlaneProducts()
+    n_fields = len(fields)
+    if n_fields == 0:
+        raise ValueError("no fields to grid")
+    dev = fields[0].device
+    if dev.type != "cuda":
+        raise _native.NativeUnavailable("grid_products_device needs device-resident (cuda) tensors")
+    if masks is None:
+        masks = [None] * n_fields
+    nz, ny, nx = (int(s) for s in geometry.grid_shape)
+    lo, hi = gp._level_window(nz, *products.window, geometry)
+    if products.colmax and lo > hi:
+        raise ValueError(f"empty level window [{lo}, {hi}]")
+    plans = {alt: gp.cappi_plan(geometry.grid_limits[0], nz, alt, products.interpolation) for alt in products.cappi}
+    for alt, plan in plans.items():
+        if plan[0] == "outside":
+            z_min, z_max = geometry.grid_limits[0]
+            gp.logger.warning(f"Altitude {alt}m is outside grid range [{z_min}, {z_max}]m")
+    needed = sorted({k for plan in plans.values() if plan[0] != "outside" for k in ((plan[1], plan[1] + 1) if plan[0] == "blend"
+                                                                                    else (plan[1],))})
+    keep_lo, n_keep = (needed[0], needed[-1] - needed[0] + 1) if needed else (0, 0)
+    n_gates = int(fields[0].numel())
+    results = []
+    with torch.cuda.device(dev):
+        use_compact = _use_compact(geometry, dev)
+        per_pass = _fields_per_pass(geometry, dev, use_compact)
+        for f0 in range(0, n_fields, per_pass):
+            f1 = min(n_fields, f0 + per_pass)
+            nf = f1 - f0
+            gridder = _cached_gridder(geometry, n_gates, nf, dev, compact=use_compact)
+            gridder.pack(fields[f0:f1], masks[f0:f1], shared_mask)
+            run_fused = gridder.has_columns_kernel if fused is None else (bool(fused) and gridder.has_columns_kernel)
+            if run_fused:
+                cmax = torch.empty((nf, ny, nx), dtype=torch.float32, device=dev) if products.colmax else None
+                carg = torch.empty((nf, ny, nx), dtype=torch.int32, device=dev) if products.argmax else None
+                planes = torch.empty((nf, n_keep, ny, nx), dtype=torch.float32, device=dev) if n_keep else None
+                if cmax is None and planes is None:      # nothing but out-of-range CAPPIs
+                    pass
+                else:
+                    gridder.apply_columns(out=None, fill_value=fill_value, level_planes=planes, keep_lo=keep_lo, col_max=cmax,
+                                          col_arg=carg, col_window=(lo, hi))
+                level = (lambda k, z: planes[k, z - keep_lo])
+            else:
+                grids = torch.empty((nf, nz, ny, nx), dtype=torch.float32, device=dev)
+                gridder.apply(grids.view(nf, -1), fill_value)
+                cmax = carg = None
+                level = (lambda k, z: grids[k, z])
+            for k in range(nf):
+                rec = {}
+                if products.colmax:
+                    if run_fused:
+                        rec["colmax"] = cmax[k]
+                        if products.argmax:
+                            rec["argmax"] = carg[k]
+                    else:
+                        got = gp._column("max", grids[k], lo, hi, None, None, None, want_arg=products.argmax)
+                        rec["colmax"], rec["argmax"] = got if products.argmax else (got, None)
+                        if not products.argmax:
+                            del rec["argmax"]
+                if products.cappi:
+                    rec["cappi"] = {}
+                    for alt, plan in plans.items():
+                        if plan[0] == "outside":
+                            rec["cappi"][alt] = torch.full((ny, nx), float("nan"), dtype=torch.float32, device=dev)
+                        elif plan[0] == "level":
+                            rec["cappi"][alt] = level(k, plan[1])
+                        else:
+                            out = torch.empty((ny, nx), dtype=torch.float32, device=dev)
+                            lo_plane = level(k, plan[1])      # levels k and k + 1 are adjacent planes of one buffer
+                            _native.check(gridder.lib.rg_cappi_lerp_f32(_native.ptr(lo_plane), ny * nx, 0,
+                                                                        float(np.float32(plan[2])), float(np.float32(plan[3])),
+                                                                        _native.ptr(out), _native.stream_ptr()), "rg_cappi_lerp_f32")
+                            rec["cappi"][alt] = out
+                results.append(rec)
+    return results
 
 
 def _to_host(t) -> np.ndarray:
