@@ -19,19 +19,9 @@ __device__ rg_u32x4 rg_buffer_load_v4u32(__amdgpu_buffer_rsrc_t, int voffset, in
 // infinity included; any other product is the IEEE one.
 __device__ float rg_fmul_legacy(float, float) __asm("llvm.amdgcn.fmul.legacy");
 
-namespace {
-
-using rg::f32x2;
-using rg::f32x4;
-using rsrc_t = __amdgpu_buffer_rsrc_t;
-constexpr int kRsrcRaw32 = 0x00020000;   // gfx9 buffer resource word 3: DATA_FORMAT = 32, untyped access
-
-__device__ __forceinline__ rsrc_t make_rsrc(const void* base, long bytes) {   // `base` and `bytes` wave-uniform
-  const unsigned nb = bytes >= 0xFFFFFFFFL ? 0xFFFFFFFFu : bytes <= 0 ? 0u : (unsigned)bytes;
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)nb, kRsrcRaw32);
-}
-
-constexpr int kH = RG_COMPACT_LINES;   // grid lines (= wavefronts) per chunk
+// Types that cross translation units (the launcher of the row-wise kernel's column mode is called from
+// rg_csr_columns.hip) live in a NAMED namespace: a function with a parameter of an anonymous-namespace type has no linkage.
+namespace rgl {
 
 // Where a chunk's wavefronts find their rows: the grid as planes x lines x rows (nz x ny x nx for a radar grid).
 // Chunk arithmetic is 32-bit on purpose: every wavefront decodes its chunk number with two divisions, and a 64-bit
@@ -48,6 +38,35 @@ struct ChunkGrid {
   unsigned grp0;            // line groups in front of this grid when it is a slab of whole planes of a larger one
                             // (rg_csr_compact_pack's plane0 * nyg; 0 for the apply kernels): the rotation counts them
 };
+
+// ---- column mode of the row-wise kernel (rg_csr_compact_apply_columns_f32) ----
+struct RowwiseColumns {
+  const int32_t* order = nullptr;   // optional: workgroup -> piece * n_cols + column (heaviest first)
+  float* planes = nullptr;          // [F][n_keep][n_xy] or null
+  float* col_val = nullptr;         // [pieces][F][n_xy] (pieces == 1: the caller's plane) or null
+  int32_t* col_arg = nullptr;       // same shape, or null
+  long n_xy = 0;
+  unsigned n_cols = 0;              // line groups per plane x segments per line
+  int pieces = 1, keep_lo = 0, n_keep = 0, col_lo = 0, col_hi = 0;
+};
+
+}  // namespace rgl
+
+namespace {
+
+using rgl::ChunkGrid;
+using rgl::RowwiseColumns;
+using rg::f32x2;
+using rg::f32x4;
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+constexpr int kRsrcRaw32 = 0x00020000;   // gfx9 buffer resource word 3: DATA_FORMAT = 32, untyped access
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, long bytes) {   // `base` and `bytes` wave-uniform
+  const unsigned nb = bytes >= 0xFFFFFFFFL ? 0xFFFFFFFFu : bytes <= 0 ? 0u : (unsigned)bytes;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)nb, kRsrcRaw32);
+}
+
+constexpr int kH = RG_COMPACT_LINES;   // grid lines (= wavefronts) per chunk
 
 // Workgroups are dealt to the 8 XCDs round-robin by blockIdx.  With nsx segments per line a multiple of 8, chunk column
 // sx would always land on XCD sx % 8 and each XCD would own one x-slab of the grid for the whole launch; rotating the
@@ -137,4 +156,27 @@ template <> struct RowwiseConfig<3> { static constexpr int kpre = RG_ROWWISE_KPR
 template <> struct RowwiseConfig<4> { static constexpr int kpre = 3, target = 8; static constexpr bool narrow = false, regs = true; };
 
 
+// ---- column mode of the row-wise kernel (rg_csr_compact_apply_columns_f32) --------------------------------------------------
+struct ColumnBest {
+  float v;     // NaN = nothing seen yet
+  int idx;     // -1 = nothing seen yet
+};
+
+// np.fmax.reduce in level order (rg_products.hip: step<true>): the first non-NaN level starts the reduction, a later one
+// replaces it only when strictly greater; NaN never wins.
+__device__ __forceinline__ void column_max_step(ColumnBest& acc, float v, int z) {
+  if (acc.idx < 0) {
+    if (!isnan(v)) { acc.v = v; acc.idx = z; }
+  } else {
+    const bool keep = acc.v >= v || isnan(v);
+    if (!keep) { acc.v = v; acc.idx = z; }
+  }
+}
+
 }  // namespace
+
+// defined in rg_csr_compact.hip (next to the kernel), called by rg_csr_columns.hip
+int rg_launch_rowwise_columns(int nf, bool i64, int window_cap, const void* indptr, const int64_t* dict_ptr, const int32_t* dict,
+                              const rgl::ChunkGrid& cg, long n_vox, const float* packed, long n_gates, float fill, float* out,
+                              hipStream_t s, const void* rec, const int64_t* rec_ptr, unsigned w_base, int rec_order,
+                              int lanes_hint, const rgl::RowwiseColumns& cols);

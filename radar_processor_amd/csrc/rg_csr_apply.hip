@@ -67,7 +67,7 @@ __device__ __forceinline__ unsigned place_block(unsigned bid, unsigned nblk) {
 
 // tuning / diagnostic flags (template parameter FLAGS)
 constexpr int kNoGather = 1;     // timing-only ablation: skip the gather (results are wrong by construction)
-constexpr int kWpb1 = 256, kWpb2 = 512, kWpb8 = 768;  // dyn kernel only: waves per workgroup (default 4)
+[[maybe_unused]] constexpr int kWpb1 = 256, kWpb2 = 512, kWpb8 = 768;  // dyn kernel only: waves per workgroup (default 4)
 constexpr int kStages3 = 1024;   // dyn kernel only: three CSR tiles in flight per wavefront instead of two
 constexpr int wpb_of(int flags) { return (flags & 768) == 256 ? 1 : (flags & 768) == 512 ? 2 : (flags & 768) == 768 ? 8 : 4; }
 

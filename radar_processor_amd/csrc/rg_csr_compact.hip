@@ -534,12 +534,18 @@ constexpr int kRowwiseChunksPerBlock = 1;   // consecutive chunks one workgroup 
 #define RG_ROWWISE_WAVES3 1
 #endif
 #define RG_ROWWISE_BOUNDS __launch_bounds__(64 * kH, (NF == 1 ? RG_ROWWISE_WAVES1 : NF == 3 ? RG_ROWWISE_WAVES3 : 1))
-template <typename IndT, int NF, int STRIDE, int DIAG = 0>
+// COLS (rg_csr_compact_apply_columns_f32, csrc/rg_csr_columns.hip): the chunks a workgroup takes one after the other are
+// not consecutive blocks of the dispatch order but the LEVELS of one column of chunks -- the same (line group, segment)
+// patch from plane z0 to z1 - 1 of its level piece -- so that lane == row sees the voxels of its (y, x) column in ascending
+// level order and can keep the column maximum / first argmax in registers and store selected levels as planes; `out`
+// may then be null (products only: the 3-D grid is never written).  Everything between a chunk's row pointers and its
+// row sums is the same code: the same bits.
+template <typename IndT, int NF, int STRIDE, int DIAG = 0, bool COLS = false>
 __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
     const IndT* __restrict__ indptr, const int64_t* __restrict__ dict_ptr, const int32_t* __restrict__ dict, ChunkGrid cg,
     const float* __restrict__ packed, unsigned last_gate, float fill, int window_cap, long n_vox, float* __restrict__ out,
     const rg_u32x4* __restrict__ rec, const int64_t* __restrict__ rec_ptr, unsigned w_base, int lanes_hint,
-    int rec_order, unsigned n_chunks, int chunks_per_block) {
+    int rec_order, unsigned n_chunks, int chunks_per_block, const RowwiseColumns cols) {
   static_assert(NF >= 1 && NF <= 4 && (STRIDE == 1 || STRIDE == 2 || STRIDE == 4), "passes of 1-4 fields");
   using Cfg = RowwiseConfig<NF>;
   constexpr int KPRE = Cfg::kpre;
@@ -564,15 +570,43 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
   // at the end of every workgroup's life.  Letting it overlap the next chunk's work changed nothing (2 / 4 / 8 / 32
   // chunks per workgroup: +0.1 ... +0.3 ms, the extra barrier): the cost is the memory system's, a trickle of writes
   // among the reads (tools/exp_placement5.py reproduces it with a bare read probe).  The loop stays as the knob it is.
+  // COLS: this workgroup's column piece (item = piece * columns + column; columns rotated per line group like the blocks of
+  // the dispatch order, so that consecutive workgroups -- consecutive XCDs -- do not pin a column of the grid to one XCD)
+  unsigned col_yg = 0, col_sx = 0, col_piece = 0;
+  int col_z0 = 0;
+  ColumnBest best[COLS ? NF : 1];
+  if constexpr (COLS) {
+    const unsigned item = cols.order ? (unsigned)cols.order[blockIdx.x] : blockIdx.x;
+    col_piece = item / cols.n_cols;
+    const unsigned q = item - col_piece * cols.n_cols;
+    col_yg = q / cg.nsx;
+    const unsigned c = q - col_yg * cg.nsx;
+    col_sx = c + (col_yg * cg.rot_step) % cg.nsx;
+    col_sx = col_sx >= cg.nsx ? col_sx - cg.nsx : col_sx;
+    col_z0 = (int)((long)col_piece * cg.n_planes / cols.pieces);
+    chunks_per_block = (int)((long)(col_piece + 1) * cg.n_planes / cols.pieces) - col_z0;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) { best[f].v = __builtin_nanf(""); best[f].idx = -1; }
+  }
+  long col_xy = 0;                                    // COLS: (y, x) of lane == row, the same on every level
+  int col_nrows = 0;
   for (int cb = 0; cb < chunks_per_block; ++cb) {
-  const unsigned bid = blockIdx.x * (unsigned)chunks_per_block + (unsigned)cb;
-  if (bid >= n_chunks) break;                         // workgroup-uniform
+  unsigned bid, chunk;
+  if constexpr (COLS) {
+    const unsigned grp = (unsigned)(col_z0 + cb) * cg.nyg + col_yg;
+    chunk = grp * cg.nsx + col_sx;
+    const unsigned shift = ((grp + cg.grp0) * cg.rot_step) % cg.nsx;      // the block whose rotated column is col_sx
+    bid = grp * cg.nsx + (col_sx >= shift ? col_sx - shift : col_sx + cg.nsx - shift);
+  } else {
+    bid = blockIdx.x * (unsigned)chunks_per_block + (unsigned)cb;
+    if (bid >= n_chunks) break;                       // workgroup-uniform
+    chunk = block_chunk(cg, bid);
+  }
   if (cb > 0) __syncthreads();                        // every wavefront is done with the previous chunk's window
   float mine_p[NF], mine_w[NF];                       // kRegs: lane == row
 #pragma unroll
   for (int f = 0; f < NF; ++f) mine_p[f] = mine_w[f] = 0.0f;
 
-  const unsigned chunk = block_chunk(cg, bid);
   const long d0 = dict_ptr[chunk];
   const int nd_all = (int)(dict_ptr[chunk + 1] - d0);
   const bool split = nd_all > 65536;
@@ -904,12 +938,38 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
       } else if constexpr (DIAG & 64) {      // grid layout, but only the 128-byte lines this wavefront owns entirely
         const long a = r0 + lane, lo = (r0 + 31) & ~31L, hi = (r0 + nrows) & ~31L;
         if (a >= lo && a < hi) out[a] = s.y > 0.0f ? (float)((double)s.x / (double)s.y) : fill;
+      } else if constexpr (COLS) {
+        const float val = s.y > 0.0f ? (float)((double)s.x / (double)s.y) : fill;
+        const int z = col_z0 + cb;
+        if (out) out[(size_t)f * n_vox + r0 + lane] = val;
+        if (cols.planes && z >= cols.keep_lo && z < cols.keep_lo + cols.n_keep)
+          cols.planes[((size_t)f * cols.n_keep + (z - cols.keep_lo)) * cols.n_xy + (r0 - (long)z * cols.n_xy) + lane] = val;
+        if (cols.col_val && z >= cols.col_lo && z <= cols.col_hi) column_max_step(best[f], val, z);
       } else {
         out[(size_t)f * n_vox + r0 + lane] = s.y > 0.0f ? (float)((double)s.x / (double)s.y) : fill;
       }
     }
   }
+  if constexpr (COLS) {
+    col_nrows = nrows;
+    col_xy = r0 - (long)(col_z0 + cb) * cols.n_xy + lane;
+    if constexpr (!kRegs) {      // the next level's rounds overwrite the row sums in LDS: this level's reads come first
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
   }   // chunks of this workgroup
+  if constexpr (COLS) {
+    if (cols.col_val && lane < col_nrows) {
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        const size_t o = ((size_t)col_piece * NF + f) * cols.n_xy + col_xy;
+        cols.col_val[o] = best[f].v;
+        if (cols.col_arg) cols.col_arg[o] = best[f].idx;
+      }
+    }
+  }
 }
 
 template <typename IndT, int NF, int DIAG = 0>
@@ -928,9 +988,56 @@ int launch_rowwise(int window_cap, const void* indptr, const int64_t* dict_ptr, 
                      dim3((unsigned)((n_chunks + chunks_per_block - 1) / chunks_per_block)), dim3(64 * kH),
                      ((size_t)(window_cap + 1) * WS * sizeof(float) + 15) / 16 * 16, s, static_cast<const IndT*>(indptr),
                      dict_ptr, dict, cg, packed, (unsigned)(n_gates - 1), fill, window_cap, n_vox, out, ps.rec, ps.rec_ptr,
-                     ps.w_base, lanes_hint, ps.order, (unsigned)n_chunks, chunks_per_block);
+                     ps.w_base, lanes_hint, ps.order, (unsigned)n_chunks, chunks_per_block, RowwiseColumns());
   return rg::check_launch("rg_csr_compact_apply_packed_f32");
 }
+
+}  // namespace
+
+// Column mode of the row-wise kernel: the launcher rg_csr_columns.hip calls (declared in rg_compact_layout.hpp).
+template <typename IndT, int NF>
+static int launch_rowwise_columns_t(int window_cap, const void* indptr, const int64_t* dict_ptr, const int32_t* dict,
+                                    const ChunkGrid& cg, long n_vox, const float* packed, long n_gates, float fill, float* out,
+                                    hipStream_t s, const void* rec, const int64_t* rec_ptr, unsigned w_base, int rec_order,
+                                    int lanes_hint, const RowwiseColumns& cols) {
+  constexpr int STRIDE = stride_for(NF);
+  constexpr int WS = RowwiseConfig<NF>::narrow ? 3 : NF == 1 ? 2 : STRIDE;
+  constexpr long kStatic = RowwiseConfig<NF>::regs ? 16 : (long)kH * 64 * NF * 8;
+  const long room = (65536 - kStatic - 256) / (4 * WS) - 1;
+  if (window_cap > room) window_cap = (int)room;
+  hipLaunchKernelGGL((csr_compact_rowwise_kernel<IndT, NF, STRIDE, 0, true>), dim3(cols.n_cols * (unsigned)cols.pieces),
+                     dim3(64 * kH), ((size_t)(window_cap + 1) * WS * sizeof(float) + 15) / 16 * 16, s,
+                     static_cast<const IndT*>(indptr), dict_ptr, dict, cg, packed, (unsigned)(n_gates - 1), fill, window_cap, n_vox,
+                     out, static_cast<const rg_u32x4*>(rec), rec_ptr, w_base, lanes_hint, rec_order,
+                     (unsigned)chunk_count(cg), 1, cols);
+  return rg::check_launch("rg_csr_compact_apply_columns_f32");
+}
+
+int rg_launch_rowwise_columns(int nf, bool i64, int window_cap, const void* indptr, const int64_t* dict_ptr, const int32_t* dict,
+                              const ChunkGrid& cg, long n_vox, const float* packed, long n_gates, float fill, float* out,
+                              hipStream_t s, const void* rec, const int64_t* rec_ptr, unsigned w_base, int rec_order,
+                              int lanes_hint, const RowwiseColumns& cols) {
+#define RG_COLS(IND_, NF_) \
+  launch_rowwise_columns_t<IND_, NF_>(window_cap, indptr, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s, rec, rec_ptr, \
+                                      w_base, rec_order, lanes_hint, cols)
+  if (i64) {
+    switch (nf) {
+      case 1: return RG_COLS(int64_t, 1);
+      case 2: return RG_COLS(int64_t, 2);
+      case 3: return RG_COLS(int64_t, 3);
+      default: return RG_COLS(int64_t, 4);
+    }
+  }
+  switch (nf) {
+    case 1: return RG_COLS(int32_t, 1);
+    case 2: return RG_COLS(int32_t, 2);
+    case 3: return RG_COLS(int32_t, 3);
+    default: return RG_COLS(int32_t, 4);
+  }
+#undef RG_COLS
+}
+
+namespace {
 
 template <typename IndT>
 int launch_rowwise_nf(int nf, int window_cap, const void* indptr, const int64_t* dict_ptr, const int32_t* dict,

@@ -34,8 +34,10 @@ def ensure(tag: str = "", defines=(), verbose: bool = True) -> str:
     os.makedirs(OUT_DIR, exist_ok=True)
     name = "libradargrid_hip_exp" + (f"_{tag}" if tag else "") + ".so"
     lib = os.path.join(OUT_DIR, name)
-    deps = rg_build.sources_and_headers()
-    if os.path.exists(lib) and all(os.path.getmtime(d) <= os.path.getmtime(lib) for d in deps):
+    # stamp = digest of the sources' CONTENTS + the defines (time stamps do not survive a snapshot copy)
+    import hashlib
+    stamp = hashlib.sha256((rg_build.source_digest() + repr(sorted(defines))).encode()).hexdigest()
+    if os.path.exists(lib) and os.path.exists(lib + ".stamp") and open(lib + ".stamp").read().strip() == stamp:
         return lib
     hipcc = rg_build._hipcc()
     flags = ["-std=c++17", "-O3", f"--offload-arch={rg_build.ARCH}", "-fPIC", f"-I{rg_build.INCLUDE}", f"-I{rg_build.CSRC}",
@@ -53,6 +55,8 @@ def ensure(tag: str = "", defines=(), verbose: bool = True) -> str:
         if p.wait() != 0:
             raise RuntimeError("experiment build failed")
     subprocess.run([hipcc, f"--offload-arch={rg_build.ARCH}", "-shared", "-fPIC", *objs, "-o", lib], check=True)
+    with open(lib + ".stamp", "w") as f:
+        f.write(stamp + "\n")
     return lib
 
 

@@ -27,7 +27,13 @@ def main():
     ap.add_argument("--pieces", default="0,1,2,4")
     ap.add_argument("--rounds", type=int, default=9)
     ap.add_argument("--layout", default="auto")
+    ap.add_argument("--exp-lib", default="", help="tag[:-DFLAG,...]: run through an experiment build (tools/build_experiments.py)")
     args = ap.parse_args()
+    if args.exp_lib:
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import build_experiments
+        tag, _, flags = args.exp_lib.partition(":")
+        build_experiments.use(tag, [f for f in flags.split(",") if f])
     import torch
     import radar_processor_amd as rg
     from radar_processor_amd import grid_products as gp, synthetic
@@ -79,8 +85,15 @@ def main():
         for p in [int(x) for x in args.pieces.split(",")]:
             variants.append((f"col/p{p}", lambda p=p: g.apply_columns(out=out, z_pieces=p)))
             variants.append((f"col/p{p}/plain", lambda p=p: g.apply_columns(out=out, z_pieces=p, ordered=False)))
+            variants.append((f"prod/p{p}/plain", lambda p=p: g.apply_columns(out=None, level_planes=planes, keep_lo=keep_lo, col_max=cmax,
+                                                                             col_arg=carg, z_pieces=p, ordered=False)))
             variants.append((f"prod/p{p}", lambda p=p: g.apply_columns(out=None, level_planes=planes, keep_lo=keep_lo, col_max=cmax,
                                                                        col_arg=carg, z_pieces=p)))
+            if args.exp_lib:       # the experiment build also carries the prefetching walk (2000) and the loader wavefront (1000)
+                for code, tag in ((2000, "walk"), (1000, "loader")):
+                    variants.append((f"col/p{p}/{tag}", lambda p=p, code=code: g.apply_columns(out=out, z_pieces=p, lanes_hint=code)))
+                    variants.append((f"prod/p{p}/{tag}", lambda p=p, code=code: g.apply_columns(
+                        out=None, level_planes=planes, keep_lo=keep_lo, col_max=cmax, col_arg=carg, z_pieces=p, lanes_hint=code)))
         times = {v[0]: [] for v in variants}
         rng = np.random.default_rng(7)
         for r in range(args.rounds + 1):
