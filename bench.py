@@ -63,6 +63,13 @@ def parse_args(argv=None):
                     help="C5: grid the batch is gridded onto (METRIC = 40x2000x2000, the metric's grid)")
     ap.add_argument("--mode", choices=("csr", "fused"), default="csr",
                     help="csr = precomputed geometry + CSR kernels (K1 / K1c); fused = rg_roi_grid_f32 (K2, no CSR)")
+    ap.add_argument("--products", choices=("auto", "fused", "separate"), default="auto",
+                    help="C5 (and the extras.c5 side measurement): how COLMAX/argmax + CAPPI are produced -- separate = grid every "
+                         "volume, then rg_column_reduce_f32 / rg_cappi_lerp_f32 on the stored grids; fused = the gridding kernel's "
+                         "products epilogue (column mode, no 3-D grid in HBM); auto = what batch.VolumeBatch picks for "
+                         "products=PlaneProducts (fused from four field-volumes per pass on)")
+    ap.add_argument("--no-c5-extra", action="store_true",
+                    help="skip the extras.c5 side measurement (8 seeded volumes per GPU through batch.VolumeBatch after the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-compact", action="store_true",
                     help="csr mode: run the standard 8-byte-per-pair kernel instead of the compact device copy of the "
@@ -339,6 +346,65 @@ def measured_read_ceiling(torch, rg, dev, buffers):
     return nbytes / (best * 1e-3) / 1e9
 
 
+def gather_per_rank(dist, backend, dev, value: float):
+    """One float from every rank, in rank order (all ranks call this; every rank gets the list)."""
+    import torch
+    world = dist.get_world_size()
+    t = torch.tensor([value], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    parts = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(parts, t)
+    return [round(float(x.item()), 4) for x in parts]
+
+
+def c5_side_measurement(args, rg, batch, synthetic, torch, dist, dev, geom_or_search, grid_geom, cfg_gates, rank, world, steps=3):
+    """north_star's batch figure next to ANY bench line: 8 seeded volumes per GPU (volume b -> rank b mod N, seed b; 64 volumes
+    on 8 GPUs) sharing one geometry, through batch.VolumeBatch, products = COLMAX + argmax + CAPPI@4000 m per volume;
+    barrier-bracketed, max over ranks.  Both ways of producing the planes are timed (epilogue of the gridding kernel / separate
+    kernels on stored grids)."""
+    per_gpu = 8
+    total = per_gpu * world
+    mine = batch.shard_indices(total, rank, world)
+    vols = [None] * total
+    for b in mine:
+        v = synthetic.make_volume(cfg_gates["n_elev"], cfg_gates["n_az"], cfg_gates["n_gates"], seed=b, fields=("DBZH",))
+        vols[b] = {"DBZH": (torch.from_numpy(np.ascontiguousarray(np.ma.getdata(v.fields["DBZH"]))).to(dev),
+                            torch.from_numpy(np.ma.getmaskarray(v.fields["DBZH"]).astype(np.uint8)).to(dev))}
+    vb = batch.VolumeBatch(geom_or_search, ("DBZH",), device=dev)
+
+    def separate(g):
+        return [(rg.column_argmax(g[k]), rg.constant_altitude_ppi(g[k], grid_geom, 4000.0)) for k in range(g.shape[0])]
+    from radar_processor_amd.gridding import PlaneProducts
+    spec = PlaneProducts(colmax=True, argmax=True, cappi=(4000.0,))
+    modes = {"separate": separate, "auto": spec}
+    out = {}
+    for name, products in modes.items():
+        if name == "auto" and vb.fused:
+            continue                                    # the CSR-free gridder has no epilogue
+        events = []
+
+        def one(timed=False):
+            return vb.grid_shard(vols, products=products, rank=rank, world_size=world, events=events if timed else None)
+        one()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one(True)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = (time.perf_counter() - t0) / steps
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        pass_ms = [a.elapsed_time(b) for a, b in events]
+        out[name] = {"ms_per_step": round(dt * 1e3, 3), "pass_ms_median": round(float(np.median(pass_ms)), 3) if pass_ms else None,
+                     "passes_per_step": len(pass_ms) / steps}
+    return out, total
+
+
 # ---------------------------------------------------------------------------------------------------------------
 def run_rank(args):
     rank = int(os.environ.get("RANK", "0"))
@@ -359,8 +425,9 @@ def run_rank(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo", timeout=timedelta(seconds=args.pg_timeout))
         dist.barrier()
+        per_rank = gather_per_rank(dist, "gloo", None, 10.0 + rank)        # the same gather the real run uses
         if rank == 0:
-            print(json.dumps({"rendezvous": "ok", "n_gpus": dist.get_world_size()}), flush=True)
+            print(json.dumps({"rendezvous": "ok", "n_gpus": dist.get_world_size(), "per_rank_kernel_ms": per_rank}), flush=True)
         dist.destroy_process_group()
         return 0
 
@@ -487,12 +554,18 @@ def run_rank(args):
 
     if c5:
         vb = batch.VolumeBatch(batch_geometry, field_names, device=dev)
+        from radar_processor_amd.gridding import PlaneProducts
 
         def reducer(g):
             return [(rg.column_argmax(g[k]), rg.constant_altitude_ppi(g[k], geom, 4000.0)) for k in range(g.shape[0])]
+        # the same planes either way (tests/test_gpu_columns.py, test_gpu_batch.py): COLMAX + argmax + CAPPI@4000 m per volume
+        c5_products = reducer if (args.products == "separate" or args.mode != "csr") else PlaneProducts(cappi=(4000.0,))
+        if args.products == "fused" and args.mode == "csr":
+            from radar_processor_amd import gridding as _gr
+            _gr._COLUMNS_FUSE_MIN_FIELDS = 1                 # force the epilogue for every pass
 
         def step(timed=False):
-            return vb.grid_shard(dev_volumes, products=reducer, rank=rank, world_size=world,
+            return vb.grid_shard(dev_volumes, products=c5_products, rank=rank, world_size=world,
                                  events=events if timed else None)
     else:
         out = torch.empty((n_ff, n_vox), dtype=torch.float32, device=dev)
@@ -541,6 +614,31 @@ def run_rank(args):
     if events:
         log(f"rank {rank}: {elapsed / args.steps * 1e3:.3f} ms/step, gridding launches min/median/mean/max "
             f"{launch_ms.min():.3f}/{np.median(launch_ms):.3f}/{kernel_ms:.3f}/{launch_ms.max():.3f} ms over {len(events)}")
+
+    kernel_ms_median_rank = float(np.median(launch_ms)) if events else float("nan")
+    per_rank_kernel_ms = ([round(kernel_ms_median_rank, 4)] if world == 1
+                          else gather_per_rank(dist, args.dist_backend, dev, kernel_ms_median_rank))
+    # ---- north_star's 64-volume figure next to every line: 8 seeded volumes per GPU through VolumeBatch, after the timed
+    # region, on every rank (max over ranks) ----------------------------------------------------------------------------
+    c5_extra = None
+    if not c5 and not args.no_c5_extra and args.config in ("METRIC", "C2"):
+        try:
+            torch.cuda.empty_cache()
+            c5_extra, c5_total = c5_side_measurement(args, rg, batch, synthetic, torch, dist, dev, batch_geometry, geom,
+                                                     synthetic.CONFIGS["C2"], rank, world)
+            c5_extra = {"volumes_total": c5_total, "volumes_per_gpu": 8, "grid": list(shape), "mode": args.mode, **c5_extra,
+                        "what": "8 seeded volumes per GPU (volume b -> rank b mod N) through batch.VolumeBatch: gridding + COLMAX/"
+                                "argmax + CAPPI@4000 m per volume, inputs resident; barrier-bracketed, max over ranks; 'auto' = "
+                                "products=PlaneProducts (epilogue of the gridding kernel where it pays), 'separate' = grids stored, "
+                                "rg_column_reduce_f32 + rg_cappi_lerp_f32 on them"}
+            for k in ("separate", "auto"):
+                if k in c5_extra:
+                    c5_extra[k]["mvoxel_s_all_gpus"] = round(c5_total * n_vox / (c5_extra[k]["ms_per_step"] * 1e-3) / 1e6, 1)
+        except Exception as exc:
+            log(f"rank {rank}: extras.c5 failed: {exc!r}")
+            c5_extra = {"failed": repr(exc)}
+            if world > 1:
+                raise                              # ranks must not diverge inside a collective
 
     # ---- the grid that was just timed is checked, outside the timed region (rank 0) ------------------------------
     # the compact kernel against the reference-format kernel on the same inputs, every voxel: the row-wise kernel to
@@ -612,10 +710,12 @@ def run_rank(args):
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "per_rank_kernel_ms": per_rank_kernel_ms,
             "config": {"workload": workload, "key": workload_key, "gates": n_gates, "voxels": n_vox,
                        "pairs": n_pairs, "fields_per_pass": fields_per_pass, "volumes_total": total_vol,
                        "ranks_seen_by_process_group": dist.get_world_size() if world > 1 else 1,
                        "checked": checked,
+                       "products": (args.products if c5 else None),
                        "record_order": (args.rec_order if args.mode == "csr" and gridder.compact is not None
                                  and gridder.packed_stream else None),
                 "step": "pack_fields + " + (("csr_compact_apply" if compact_on else "csr_apply") if args.mode == "csr"
@@ -718,6 +818,9 @@ def run_rank(args):
                                                 "buffers (own stream); rank 0 only"}
             except Exception as exc:
                 log(f"end-to-end leg failed: {exc!r}")
+        result["extras"] = {"geometry_build_s": round(t_geom, 3)}
+        if c5_extra is not None:
+            result["extras"]["c5"] = c5_extra
         if n_gpus == 1 and args.mode == "csr" and not c5:
             # side measurement on the same inputs (not part of `value`): the CSR-free fused gridder (K2)
             try:
@@ -731,10 +834,10 @@ def run_rank(args):
                 b_ev.record()
                 b_ev.synchronize()
                 k2_ms = a_ev.elapsed_time(b_ev) / 3
-                result["extras"] = {"geometry_build_s": round(t_geom, 3),
+                result.setdefault("extras", {}).update({"geometry_build_s": round(t_geom, 3),
                                     "roi_grid_fused_ms": round(k2_ms, 3),
                                     "roi_grid_fused_mvoxel_s": round(n_ff * n_vox / k2_ms / 1e3, 1),
-                                    "note": "rg_roi_grid_f32: same volume gridded without a CSR (search fused in)"}
+                                    "note": "rg_roi_grid_f32: same volume gridded without a CSR (search fused in)"})
                 del search
             except Exception as exc:
                 log(f"fused side measurement failed: {exc!r}")

@@ -388,14 +388,14 @@ int rg_csr_compact_apply_packed_f32(const void* indptr, int32_t indptr_is_i64, c
                                     rg_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
- * K1p  the row-wise kernel with workgroups PERSISTENT over a column of chunks, and an optional products epilogue.
+ * K1p  the row-wise kernel in COLUMN MODE, with an optional products epilogue.
  * Replaces, in one pass over the packed records: radar_grid/interpolate.py:69-104 (apply_geometry) / :137-140
  * (apply_geometry_multi) and -- when the caller keeps 2-D products only -- the read-back of the 3-D grid by
  * radar_grid/products.py:462-490 (column_max over a level window) and :361-412 (CAPPI: the two bracketing levels).
- * A workgroup walks the chunks (plane z, line group yg, segment sx) of ONE (yg, sx) through the planes of its level piece:
- * four wavefronts stream the records exactly as rg_csr_compact_apply_packed_f32 (tile = 0) does, a fifth gathers the NEXT
- * chunk's field window into a second LDS window and publishes the chunk after that one's row pointers, so the per-chunk
- * chain of dependent loads leaves the critical path and the record stream runs on across chunk boundaries.
+ * A workgroup walks the chunks (plane z, line group yg, segment sx) of ONE (yg, sx) through the planes of its level piece,
+ * each chunk exactly as rg_csr_compact_apply_packed_f32 (tile = 0) processes it, so lane == row sees its (y, x) column in
+ * ascending level order.  Measured: it pays from four field-volumes per pass on (the store it saves is about what walking
+ * columns instead of sweeping the grid costs) and always in memory -- no n_fields x 4 x n_vox bytes of grid.
  * Arguments up to fill_value: as rg_csr_compact_apply_packed_f32 (either record order is accepted).
  *   out           [n_fields][n_vox] 3-D grids, or NULL: the grids are not stored (products only);
  *   level_planes  [n_fields][n_keep][ny*nx] or NULL: planes keep_lo .. keep_lo + n_keep - 1 of every field's grid (what a

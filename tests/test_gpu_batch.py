@@ -70,6 +70,16 @@ def test_volume_batch_grid_shard_under_rccl(nccl_group, tmp_path):
                 np.testing.assert_array_equal(np.isnan(g), np.isnan(want))
                 scale = float(np.abs(data[np.isfinite(data) & ~mask]).max())
                 np.testing.assert_allclose(g, want, rtol=1e-5, atol=ATOL_FRAC * scale, equal_nan=True)
+        # products as a declaration (PlaneProducts) instead of a reducer: the same planes as reducing the grids by hand
+        spec = rg.PlaneProducts(cappi=(3000.0,), z_min_idx=1, z_max_idx=3)
+        recs = vb.grid_shard(volumes, products=spec)
+        for b in range(5):
+            for i in range(2):
+                want_max, want_arg = rg.column_argmax(got[b][i], z_min_idx=1, z_max_idx=3)
+                assert torch.equal(recs[b][i]["colmax"].view(torch.int32), want_max.view(torch.int32))
+                assert torch.equal(recs[b][i]["argmax"], want_arg)
+                want_cap = rg.constant_altitude_ppi(got[b][i], geom, 3000.0)
+                assert torch.equal(recs[b][i]["cappi"][3000.0].view(torch.int32), want_cap.contiguous().view(torch.int32))
     planes = vb.grid_shard(volumes, products=lambda g: rg.column_max(g[0]))
     local = torch.stack([planes[b] for b in range(5)])
     mine = torch.where(torch.isnan(local), torch.full_like(local, float("-inf")), local).amax(dim=0)
@@ -120,6 +130,24 @@ def test_bench_spawns_its_own_ranks():
     assert line["n_gpus"] == 2 and line["config"]["ranks_seen_by_process_group"] == 2
     assert line["config"]["volumes_total"] == 4
     assert "skipped" in line["cpu_baseline"]            # N > 1: the host-core baseline belongs to the N = 1 line
+
+
+def test_two_rank_line_carries_per_rank_kernel_times_and_the_config5_side_measurement():
+    """What the driver's scaling run needs in every `--gpus N` line: each rank's median kernel time, so that an
+    N-GPU efficiency can be separated from the two-cluster placement lottery of the single-field kernel, and
+    north_star's batch figure (8 seeded volumes per GPU through batch.VolumeBatch, max over ranks) as `extras.c5` -- here two
+    ranks sharing the one card over gloo, on the config-2 grid."""
+    line = _run_bench(["--gpus", "2", "--dist-backend", "gloo", "--share-device", "--config", "C2", "--no-cpu-baseline"])
+    assert line["n_gpus"] == 2 and line["config"]["ranks_seen_by_process_group"] == 2
+    per_rank = line["per_rank_kernel_ms"]
+    assert len(per_rank) == 2 and all(0 < v < 100 for v in per_rank)
+    c5 = line["extras"]["c5"]
+    assert c5["volumes_total"] == 16 and c5["volumes_per_gpu"] == 8
+    for mode in ("separate", "auto"):
+        assert c5[mode]["ms_per_step"] > 0 and c5[mode]["passes_per_step"] == 2 and c5[mode]["mvoxel_s_all_gpus"] > 0
+    # ... and the products mode of the config-5 line itself is recorded
+    one = _run_bench(["--gpus", "1", "--config", "C5", "--c5-grid", "C2", "--volumes-per-gpu", "4", "--products", "fused"])
+    assert one["config"]["products"] == "fused" and one["per_rank_kernel_ms"] == [one["roofline"]["kernel_ms_median"]]
 
 
 def test_bench_refuses_mismatched_world():

@@ -307,9 +307,9 @@ class TestNativeLibrary:
         if nm.returncode == 0:       # host-side kernel stubs carry the template arguments
             rows = [l for l in nm.stdout.splitlines() if "csr_compact_rowwise_kernel<" in l]
             assert rows, "row-wise kernel not found in the symbol table"
-            for l in rows:           # <IndT, NF, STRIDE, DIAG>: DIAG must be 0 everywhere
+            for l in rows:           # <IndT, NF, STRIDE, DIAG, COLS>: DIAG must be 0 everywhere
                 args = l[l.index("csr_compact_rowwise_kernel<") + len("csr_compact_rowwise_kernel<"):].split(">(")[0].split(",")
-                assert args[-1].strip() == "0", l
+                assert len(args) == 5 and args[3].strip() == "0", l
 
     def test_ensure_built_rebuilds_a_stale_library(self, tmp_path, monkeypatch):
         """ensure_built() compiles when the library is missing AND when it was built from other sources or headers than
@@ -423,7 +423,15 @@ class TestBenchLauncher:
     def test_launcher_passes_rank0_line_through(self):
         res = self._run(["--gpus", "2", "--share-device", "--rendezvous-only"], {})
         assert res.returncode == 0, res.stderr[-600:]
-        assert json.loads(res.stdout.decode().strip().splitlines()[-1]) == {"rendezvous": "ok", "n_gpus": 2}
+        line = json.loads(res.stdout.decode().strip().splitlines()[-1])
+        # one entry per rank, in rank order (the gather every real N-GPU line uses for per_rank_kernel_ms)
+        assert line == {"rendezvous": "ok", "n_gpus": 2, "per_rank_kernel_ms": [10.0, 11.0]}
+
+    def test_per_rank_list_has_one_entry_per_rank(self):
+        res = self._run(["--gpus", "3", "--share-device", "--rendezvous-only"], {})
+        assert res.returncode == 0, res.stderr.decode()[-2000:]
+        line = json.loads(res.stdout.decode().strip().splitlines()[-1])
+        assert line["n_gpus"] == 3 and line["per_rank_kernel_ms"] == [10.0, 11.0, 12.0]
 
     def test_parent_refuses_more_ranks_than_gpus(self):
         import torch

@@ -89,11 +89,6 @@ def main():
                                                                              col_arg=carg, z_pieces=p, ordered=False)))
             variants.append((f"prod/p{p}", lambda p=p: g.apply_columns(out=None, level_planes=planes, keep_lo=keep_lo, col_max=cmax,
                                                                        col_arg=carg, z_pieces=p)))
-            if args.exp_lib:       # the experiment build also carries the prefetching walk (2000) and the loader wavefront (1000)
-                for code, tag in ((2000, "walk"), (1000, "loader")):
-                    variants.append((f"col/p{p}/{tag}", lambda p=p, code=code: g.apply_columns(out=out, z_pieces=p, lanes_hint=code)))
-                    variants.append((f"prod/p{p}/{tag}", lambda p=p, code=code: g.apply_columns(
-                        out=None, level_planes=planes, keep_lo=keep_lo, col_max=cmax, col_arg=carg, z_pieces=p, lanes_hint=code)))
         times = {v[0]: [] for v in variants}
         rng = np.random.default_rng(7)
         for r in range(args.rounds + 1):
