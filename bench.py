@@ -564,6 +564,13 @@ def run_rank(args):
             from radar_processor_amd import gridding as _gr
             _gr._COLUMNS_FUSE_MIN_FIELDS = 1                 # force the epilogue for every pass
 
+        if args.mode == "csr" and isinstance(c5_products, PlaneProducts) and gridder.has_columns_kernel:
+            from radar_processor_amd import gridding as _gr
+            if fields_per_pass >= _gr._COLUMNS_FUSE_MIN_FIELDS:      # the passes run the products epilogue: no 3-D store
+                algo_bytes = gridder.columns_bytes(store_grid=False, n_keep=2, colmax=True)
+                ref_format_bytes -= fields_per_pass * 4 * n_vox
+                kernel_name = "csr_compact_rowwise_kernel (column mode, products epilogue)"
+
         def step(timed=False):
             return vb.grid_shard(dev_volumes, products=c5_products, rank=rank, world_size=world,
                                  events=events if timed else None)
@@ -681,6 +688,48 @@ def run_rank(args):
                     "compact kernel and reference-format kernel disagree on the timed grid"
                 checked += "; compact tile kernel == rg_csr_apply_f32 bit for bit on all of them"
             del ref_out, ref_gridder
+        elif gridder.compact is not None and kernel_name == "csr_compact_rowwise_kernel":
+            # Packed-only geometry (layout 'auto' from 50 M pairs on): the reference's index / weight arrays do not exist.
+            # (1) the TILE kernel over the same records (rg_csr_apply_f32's order, its bits on every geometry the tests
+            # compare them on) against the row-wise grid on every voxel; (2) bands of whole (z, y) rows -- the grid's first
+            # rows, its middle, its last -- DECODED from the records back into the reference's CSR (CompactCSR.decode /
+            # decode_weights: bit-exact) and gridded by rg_csr_apply_f32 itself as a stand-alone geometry, against both.
+            from radar_processor_amd.grid_geometry import DeviceCSR, GridGeometry
+            scale = max(float(f_t[torch.isfinite(f_t)].abs().max()) for f_t in fields_d)
+            tile_out = torch.empty_like(out)
+            gridder.tile = 384
+            gridder.apply(tile_out)
+            gridder.tile = 0
+            assert bool(torch.equal(torch.isnan(tile_out), torch.isnan(out))), "filled voxels differ between the two kernels"
+            excess = torch.nan_to_num((out - tile_out).abs() - 1e-5 * tile_out.abs(), nan=0.0)
+            assert float(excess.max()) <= 2e-6 * scale, "row-wise and tile kernel differ beyond 1e-5 rel + 2e-6 abs"
+            sig = tile_out.abs() > 1e-3 * scale
+            rel = float(((out - tile_out).abs()[sig] / tile_out.abs()[sig]).max())
+            assert rel <= 1e-5, "row-wise kernel beyond 1e-5 relative on significant voxels"
+            del excess, sig
+            nz_, ny_, nx_ = shape
+            band = 24                                         # (z, y) rows per band: ~50 k voxels, a few M pairs each
+            rows_total = nz_ * ny_
+            bands, decoded_pairs = [0, (nz_ // 2) * ny_ + ny_ // 2 - band // 2, rows_total - band], 0
+            for r_lo in bands:
+                v0, v1 = r_lo * nx_, (r_lo + band) * nx_
+                ip = csr_now.indptr[v0:v1 + 1].to(torch.int64)
+                sub = DeviceCSR((ip - ip[0]).to(torch.int32), gridder.compact.decode(csr_now, v0, v1),
+                                gridder.compact.decode_weights(csr_now, v0, v1).clone(), csr_now.max_gate)
+                decoded_pairs += sub.n_pairs
+                sub_geom = GridGeometry.from_device((1, band, nx_), ((0.0, 0.0), limits[1], limits[2]), sub, geom.toa)
+                k1 = CsrGridder(sub_geom, n_gates, fields_per_pass, device=dev, compact=False)
+                k1.packed = gridder.packed                    # the fields as packed for the timed pass
+                k1_out = torch.empty((n_ff, band * nx_), dtype=torch.float32, device=dev)
+                k1.apply(k1_out)
+                assert bool(torch.equal(k1_out.view(torch.int32), tile_out[:, v0:v1].contiguous().view(torch.int32))), \
+                    "tile kernel over the packed records and rg_csr_apply_f32 on the decoded rows disagree"
+                del sub, sub_geom, k1, k1_out
+            checked += (f"; packed-only geometry: row-wise kernel vs the tile kernel over the same records on all of them (same "
+                        f"voxels filled, |diff| <= 1e-5*|ref| + 2e-6*max|field|, worst relative deviation where |ref| > "
+                        f"1e-3*max|field|: {rel:.1e}); tile kernel == rg_csr_apply_f32 bit for bit on {len(bands)} bands of {band} "
+                        f"whole (z,y) rows decoded back into the reference's CSR ({decoded_pairs} pairs)")
+            del tile_out
         del nonempty, filled
     launches_per_step = len(events) / max(args.steps, 1)
 
@@ -818,7 +867,16 @@ def run_rank(args):
                                                 "buffers (own stream); rank 0 only"}
             except Exception as exc:
                 log(f"end-to-end leg failed: {exc!r}")
-        result["extras"] = {"geometry_build_s": round(t_geom, 3)}
+        resident = None
+        if gridder is not None:
+            resident = gridder.csr.nbytes() + (gridder.compact.nbytes() if gridder.compact is not None else 0)
+        elif search is not None:
+            resident = search.sorted_gates.numel() * 4 + search.cell_start.numel() * 4
+        result["extras"] = {"geometry_build_s": round(t_geom, 3),
+                            "geometry_resident_gb": round(resident / 1e9, 2) if resident is not None else None,
+                            "geometry_layout": (None if gridder is None else "packed" if gridder.csr.weights is None else
+                                                "compact" if gridder.csr.gate_indices is None else "csr+compact"
+                                                if gridder.compact is not None else "csr")}
         if c5_extra is not None:
             result["extras"]["c5"] = c5_extra
         if n_gpus == 1 and args.mode == "csr" and not c5:

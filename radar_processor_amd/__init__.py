@@ -15,7 +15,7 @@ without the built library and a HIP device every compute entry point raises ``Na
 from ._native import NativeError, NativeUnavailable, load_library
 from .gate_filters import GateFilter, GridFilter, create_mask_from_filter, device_gate_mask
 from .geometry_builder import RoiSearch, compute_grid_geometry
-from .grid_geometry import DeviceCSR, GridGeometry, load_geometry, save_geometry
+from .grid_geometry import (DeviceCSR, GridGeometry, load_device_layout, load_geometry, save_device_layout, save_geometry)
 from .grid_products import (EARTH_RADIUS, EFFECTIVE_RADIUS_FACTOR, column_argmax, column_max, column_mean,
                             column_min, compute_beam_height, compute_beam_height_flat, compute_beam_height_simple,
                             constant_altitude_ppi, constant_elevation_ppi, get_beam_height_difference,
@@ -44,7 +44,7 @@ __all__ = [
     # 2-D raster stage of radar_processor (utils.py:336-387, processor.py:480-551, :802-886)
     "collapse_field_3d_to_2d", "collapse_grid_to_2d", "apply_filter_masks",
     # build-specific additions
-    "column_argmax", "grid_fields_device", "grid_products_device", "PlaneProducts", "roi_grid_fields_device", "build_grid3d_package", "device_gate_mask", "RoiSearch", "DeviceCSR",
+    "save_device_layout", "load_device_layout", "column_argmax", "grid_fields_device", "grid_products_device", "PlaneProducts", "roi_grid_fields_device", "build_grid3d_package", "device_gate_mask", "RoiSearch", "DeviceCSR",
     "collapse_plane_device", "plane_filter_device", "PlaneTest", "colormap_lut", "colormap_rgba_device",
     "NativeUnavailable", "NativeError", "load_library",
 ]

@@ -168,6 +168,7 @@ class RoiSearch:
 # multiple of 8 (the kernels OR it back in) and at most 7 below the largest exponent a weight can have.  barnes2:
 # exp(-4)+1e-5 = 2^-6 * 1.17 (exponent 121) .. 1+1e-5 (127); nearest: 1.0 (127)
 _PACK_BASE_EXPONENT = {"barnes2": 120, "nearest": 120}
+_AUTO_PACKED_MIN_PAIRS = 50_000_000      # layout="auto": from here on the packed layout alone (gridding._COMPACT_MIN_PAIRS)
 
 
 def _build_compact_only(search: "RoiSearch", weighting: str, pairs_per_slab: int = 1_200_000_000, packed: bool = False):
@@ -297,8 +298,9 @@ def compute_grid_geometry(
     pool -- the build runs on the GPU.  The result is device resident; ``.indptr`` / ``.gate_indices`` /
     ``.weights`` copy to the host on first access (``save_geometry`` does that).
 
-    ``layout`` (build-specific): ``"csr"`` keeps the reference's three arrays in HBM; ``"auto"`` does so whenever
-    they and their compact copy fit the free memory, and otherwise falls to ``"compact"``, which keeps
+    ``layout`` (build-specific): ``"csr"`` keeps the reference's three arrays in HBM; ``"auto"`` does so for geometries
+    below 50 M pairs and for weights that are not codable (while they fit), builds ``"packed"`` for every larger Barnes /
+    uniform geometry, and otherwise falls to ``"compact"``, which keeps
     ``indptr``, ``weights`` and the compact copy of the gate indices only (``grid_geometry.CompactCSR``, 6.2 instead
     of 8 bytes per pair), or to ``"packed"``, which keeps ``indptr`` and the packed pair stream only (positions and
     losslessly coded weights of three pairs per 16-byte record: 5.4 bytes per pair; Barnes and uniform weights) -- for
@@ -324,14 +326,19 @@ def compute_grid_geometry(
     if layout not in ("csr", "compact", "packed", "auto"):
         raise ValueError("layout must be 'csr', 'compact', 'packed' or 'auto'")
     if layout == "auto":
-        # the reference's arrays whenever they AND their compact copy fit (8 + 2.2 bytes per pair: gridding then runs
-        # through the copy and the int32 index array stays available), the compact layout alone (6.2 bytes per pair)
-        # for geometries where they do not (config 4: 33 G pairs = 266 GB of standard CSR on a 288 GB device)
+        # Large geometries whose weights fit the 26-bit code (Barnes, uniform) are built in the packed layout ALONE: row
+        # pointers + dictionaries + 16-byte records, 5.4 bytes per pair -- it is what every gridding pass of 1-4 fields reads
+        # anyway, the reference's index and weight arrays are rebuilt from it on demand, bit for bit (CompactCSR.decode /
+        # decode_weights: save_geometry, the CPU baseline, the bench's post-check), and a process touches 47 GB instead of
+        # 115 GB for the bench geometry (first-touch allocation is what a build's wall time consists of).  Geometries below
+        # 50 M pairs grid in well under a millisecond either way and keep the reference's arrays; non-codable weights
+        # (Cressman) keep them too when they and their compact copy fit, and fall to the compact layout otherwise.
         n_pairs = search.count_pairs()
         free_b, _ = _native.torch_mod().cuda.mem_get_info(search.dev)
-        # ... (+5.4 bytes per pair for the packed stream when there is room for it as well)
-        layout = ("csr" if 10.4 * n_pairs + (10 << 30) <= free_b
-                  else "packed" if weighting in _PACK_BASE_EXPONENT else "compact")
+        if n_pairs >= _AUTO_PACKED_MIN_PAIRS and weighting in _PACK_BASE_EXPONENT:
+            layout = "packed"
+        else:
+            layout = "csr" if 10.4 * n_pairs + (10 << 30) <= free_b else "compact"
         logger.info(f"{n_pairs:,} pairs, {free_b / 1e9:.0f} GB free -> layout '{layout}'")
     if layout == "packed":
         built = _build_compact_only(search, weighting, packed=True)

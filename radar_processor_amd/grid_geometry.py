@@ -628,3 +628,70 @@ def load_geometry(filepath: str) -> GridGeometry:
         )
     logger.info(f"Loaded geometry: {geometry.memory_usage_mb():.1f} MB in memory, toa={geometry.toa}m")
     return geometry
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# Sidecar of the device layout.  The reference's expensive precompute is a file (radar_grid/geometry.py:94-150) and that
+# file -- the nine-key .npz above -- stays the interchange format.  What this build derives from it for large geometries
+# (the compact copy: dictionaries + packed records) can be kept NEXT to it, so that a process that loads the .npz does
+# not derive it again: an uncompressed .npz keyed by the sha256 of the reference arrays it was derived from, read with
+# numpy.load(allow_pickle=False).  (A geometry built on the GPU from gate coordinates needs none of this: rebuilding the
+# bench geometry takes 0.3 s of kernels, less than reading any file of its size.)
+# --------------------------------------------------------------------------------------------------------------------
+def _reference_arrays_digest(geometry: GridGeometry) -> str:
+    import hashlib
+    h = hashlib.sha256()
+    h.update(repr((tuple(int(v) for v in geometry.grid_shape), _native.RG_COMPACT_LINES, _native.RG_COMPACT_ROTATION)).encode())
+    for arr in (geometry.indptr, geometry.gate_indices, geometry.weights):
+        a = np.ascontiguousarray(arr)
+        h.update(str(a.dtype).encode() + str(a.shape).encode())
+        h.update(memoryview(a).cast("B"))
+    return h.hexdigest()
+
+
+def save_device_layout(geometry: GridGeometry, filepath: str, device=None) -> bool:
+    """Write the compact copy of ``geometry`` (dictionaries, packed records or plain positions) as a sidecar ``.npz`` keyed by
+    the digest of its reference arrays.  Returns ``False`` (nothing written) when the geometry has no compact copy."""
+    compact = geometry.device_compact(device)
+    if compact is None:
+        return False
+    csr = geometry.device_csr(device)
+    compact.ensure_packed(csr)
+    arrays = dict(key=np.frombuffer(_reference_arrays_digest(geometry).encode(), dtype=np.uint8),
+                  grid_shape=np.array(compact.grid_shape, dtype=np.int64), dict_ptr=compact.dict_ptr.cpu().numpy(),
+                  dict=compact.dict.cpu().numpy(), max_dict=np.array([compact.max_dict]), window_cap=np.array([compact.window_cap]),
+                  chunk_pairs=compact.chunk_pairs.cpu().numpy(), chunk_counts=compact.chunk_counts.cpu().numpy())
+    if compact.rec is not None:
+        arrays.update(rec=compact.rec.cpu().numpy(), rec_ptr=compact.rec_ptr.cpu().numpy(),
+                      rec_order=np.array([compact.rec_order]), w_base=np.array([compact.w_base], dtype=np.uint32))
+    if compact.local_idx is not None:
+        arrays["local_idx"] = compact.local_idx.cpu().numpy()
+    np.savez(filepath, **arrays)
+    logger.info(f"Saved device layout to {filepath} ({os.path.getsize(filepath) / 1e6:.1f} MB)")
+    return True
+
+
+def load_device_layout(geometry: GridGeometry, filepath: str, device=None) -> bool:
+    """Attach the compact copy stored by :func:`save_device_layout` to ``geometry`` instead of deriving it again.  The
+    sidecar is used only when its key matches the geometry's reference arrays (same CSR, same chunk layout); returns
+    whether it was."""
+    torch = _native.torch_mod()
+    if not os.path.exists(filepath):
+        return False
+    with np.load(filepath, allow_pickle=False) as data:
+        if bytes(data["key"]).decode() != _reference_arrays_digest(geometry):
+            logger.warning(f"{filepath} was derived from another geometry: ignored")
+            return False
+        csr = geometry.device_csr(device)
+        dev = csr.indptr.device
+        up = lambda name: torch.from_numpy(np.ascontiguousarray(data[name])).to(dev)       # noqa: E731
+        compact = CompactCSR(up("local_idx") if "local_idx" in data else None, up("dict_ptr"), up("dict"), int(data["max_dict"][0]),
+                             int(data["window_cap"][0]), tuple(int(v) for v in data["grid_shape"]), up("chunk_pairs"),
+                             up("chunk_counts"))
+        if "rec" in data:
+            compact.rec, compact.rec_ptr = up("rec"), up("rec_ptr")
+            compact.rec_order, compact.w_base = int(data["rec_order"][0]), int(data["w_base"][0])
+            compact._pack_tried = True
+    geometry._compact = (csr, compact)
+    logger.info(f"Device layout attached from {filepath}: {compact.nbytes() / 1e6:.1f} MB")
+    return True

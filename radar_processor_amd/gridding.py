@@ -254,6 +254,16 @@ class CsrGridder:
             pieces, _native.ptr(order), _native.ptr(ws), 0 if ws is None else int(ws.numel()), int(lanes_hint),
             _native.stream_ptr()), "rg_csr_compact_apply_columns_f32")
 
+    def columns_bytes(self, store_grid: bool, n_keep: int = 0, colmax: bool = False) -> Optional[int]:
+        """Bytes one ``apply_columns`` launch must move: the compact kernel's, minus the grids that are not stored, plus the
+        kept planes and the (max, arg) planes."""
+        base = self.compact_bytes()
+        if base is None:
+            return None
+        nz, ny, nx = self.grid_shape
+        return (base - (0 if store_grid else self.n_fields * 4 * self.n_vox)
+                + self.n_fields * 4 * ny * nx * (int(n_keep) + (2 if colmax else 0)))
+
     def algorithmic_bytes(self) -> int:
         """Bytes one ``apply`` launch must move: index + weight per pair, the row pointers,
         each field's values + mask once, each output grid once."""

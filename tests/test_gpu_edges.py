@@ -622,3 +622,44 @@ def test_product_library_refuses_timing_only_and_experiment_tile_codes(rg):
         st = lib.rg_csr_apply_f32_ex(P(ip), 0, P(ip), P(buf), 64, 0, 64, P(buf), 1, 1, 64, 0.0, P(buf), variant, 0)
         assert st == _native.RG_EINVAL, (variant, st)
     torch.cuda.synchronize()
+
+
+def test_device_layout_sidecar_round_trip(rg, tmp_path):
+    """The compact copy (dictionaries + packed records) saved next to the reference .npz and attached to a freshly loaded
+    geometry instead of being derived again: the same bits out of the row-wise and the tile kernel; a sidecar derived from
+    another geometry is refused (geometry.py:94-150 stays the interchange format; the sidecar is this build's own)."""
+    import torch
+    from radar_processor_amd.gridding import CsrGridder
+    gx, gy, gz, val, mask = _cloud(3, 6000)
+    shape, limits = (3, 9, 130), ((0.0, 8e3), (-20e3, 20e3), (-20e3, 20e3))
+    geom = rg.compute_grid_geometry(gx, gy, gz, shape, limits, str(tmp_path), min_radius=900.0, beam_factor=0.05)
+    dev = torch.device("cuda")
+    npz, side = str(tmp_path / "g.npz"), str(tmp_path / "g.layout.npz")
+    rg.save_geometry(geom, npz)
+    assert rg.save_device_layout(geom, side)
+    f_t, m_t = torch.from_numpy(val).to(dev), torch.from_numpy(mask.astype(np.uint8)).to(dev)
+
+    def grids(g, attach):
+        if attach is not None:
+            assert rg.load_device_layout(g, attach) is True
+        compact = g.device_compact(dev)
+        assert compact is not None and compact.ensure_packed(g.device_csr(dev))
+        gr = CsrGridder(g, val.size, 1, device=dev)
+        gr.compact, gr.window, gr.packed_stream = compact, compact.window_for(1), True
+        gr.pack([f_t], [m_t])
+        out = []
+        for tile in (0, 384):
+            gr.tile = tile
+            o = torch.empty((1, gr.n_vox), dtype=torch.float32, device=dev)
+            gr.apply(o)
+            out.append(o)
+        return out, compact
+    want, c0 = grids(geom, None)
+    back = rg.load_geometry(npz)
+    got, c1 = grids(back, side)
+    assert c1 is not c0 and torch.equal(c1.rec, c0.rec) and torch.equal(c1.dict, c0.dict) and c1.w_base == c0.w_base
+    for a, b in zip(got, want):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    other = rg.compute_grid_geometry(gx, gy, gz, shape, limits, str(tmp_path), min_radius=700.0, beam_factor=0.05)
+    assert rg.load_device_layout(other, side) is False                      # another CSR: key mismatch
+    assert rg.load_device_layout(back, str(tmp_path / "missing.npz")) is False

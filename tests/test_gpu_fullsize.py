@@ -368,8 +368,8 @@ def test_c2_passes_use_the_compact_copy_from_the_first(c2):
 def test_c2_compact_only_layout(c2, tmp_path):
     """compute_grid_geometry(layout="compact"): the int32 index array is never materialised for the whole grid; row
     pointers and weights equal the standard build bit for bit, the decoded indices equal its gate_indices, gridding
-    gives the same values (to float32 rounding: its passes run the row-wise kernel), and layout="auto" keeps the
-    standard arrays when they fit."""
+    gives the same values (to float32 rounding: its passes run the row-wise kernel); layout="auto" builds the packed
+    layout alone from 50 M codable pairs on and keeps the reference's arrays below."""
     rg, torch, dev, vol, cfg = c2["rg"], c2["torch"], c2["dev"], c2["vol"], c2["cfg"]
     std = c2["geom"].device_csr(dev)
     geom = rg.compute_grid_geometry(vol.gate_x, vol.gate_y, vol.gate_z, cfg["grid_shape"], cfg["grid_limits"],
@@ -403,7 +403,13 @@ def test_c2_compact_only_layout(c2, tmp_path):
     assert torch.equal(got_t.view(torch.int32), want2.view(torch.int32))
     auto = rg.compute_grid_geometry(vol.gate_x, vol.gate_y, vol.gate_z, cfg["grid_shape"], cfg["grid_limits"],
                                     str(tmp_path), layout="auto")
-    assert auto.device_csr(dev).gate_indices is not None
+    # 0.87 G pairs of Barnes weights: 'auto' builds the packed layout alone (>= 50 M pairs, codable) ...
+    a_csr = auto.device_csr(dev)
+    assert a_csr.gate_indices is None and a_csr.weights is None and auto.device_compact(dev).rec is not None
+    # ... from which the reference's arrays come back bit for bit on demand
+    assert torch.equal(auto.device_compact(dev).decode(a_csr, 0, 5000), std.gate_indices[:int(std.indptr[5000])])
+    small = rg.compute_grid_geometry(vol.gate_x, vol.gate_y, vol.gate_z, (2, 40, 40), cfg["grid_limits"], str(tmp_path), layout="auto")
+    assert small.device_csr(dev).gate_indices is not None and small.n_pairs() < 50_000_000      # small: the reference's arrays
     with pytest.raises(ValueError):
         rg.compute_grid_geometry(vol.gate_x, vol.gate_y, vol.gate_z, cfg["grid_shape"], cfg["grid_limits"],
                                  str(tmp_path), layout="coo")
