@@ -66,8 +66,8 @@ def parse_args(argv=None):
     ap.add_argument("--products", choices=("auto", "fused", "separate"), default="auto",
                     help="C5 (and the extras.c5 side measurement): how COLMAX/argmax + CAPPI are produced -- separate = grid every "
                          "volume, then rg_column_reduce_f32 / rg_cappi_lerp_f32 on the stored grids; fused = the gridding kernel's "
-                         "products epilogue (column mode, no 3-D grid in HBM); auto = what batch.VolumeBatch picks for "
-                         "products=PlaneProducts (fused from four field-volumes per pass on)")
+                         "products epilogue (column mode, no 3-D grid in HBM: the memory-saving way, about as fast); auto = what "
+                         "batch.VolumeBatch does for products=PlaneProducts (separate: measured at least as fast)")
     ap.add_argument("--no-c5-extra", action="store_true",
                     help="skip the extras.c5 side measurement (8 seeded volumes per GPU through batch.VolumeBatch after the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -375,11 +375,14 @@ def c5_side_measurement(args, rg, batch, synthetic, torch, dist, dev, geom_or_se
         return [(rg.column_argmax(g[k]), rg.constant_altitude_ppi(g[k], grid_geom, 4000.0)) for k in range(g.shape[0])]
     from radar_processor_amd.gridding import PlaneProducts
     spec = PlaneProducts(colmax=True, argmax=True, cappi=(4000.0,))
-    modes = {"separate": separate, "auto": spec}
+    from radar_processor_amd import gridding as _gr
+    modes = {"separate": separate, "fused": spec}
     out = {}
+    default_min = _gr._COLUMNS_FUSE_MIN_FIELDS
     for name, products in modes.items():
-        if name == "auto" and vb.fused:
+        if name == "fused" and vb.fused:
             continue                                    # the CSR-free gridder has no epilogue
+        _gr._COLUMNS_FUSE_MIN_FIELDS = 1 if name == "fused" else default_min     # 'fused': the epilogue for every pass
         events = []
 
         def one(timed=False):
@@ -402,6 +405,7 @@ def c5_side_measurement(args, rg, batch, synthetic, torch, dist, dev, geom_or_se
         pass_ms = [a.elapsed_time(b) for a, b in events]
         out[name] = {"ms_per_step": round(dt * 1e3, 3), "pass_ms_median": round(float(np.median(pass_ms)), 3) if pass_ms else None,
                      "passes_per_step": len(pass_ms) / steps}
+    _gr._COLUMNS_FUSE_MIN_FIELDS = default_min
     return out, total
 
 
@@ -566,7 +570,7 @@ def run_rank(args):
 
         if args.mode == "csr" and isinstance(c5_products, PlaneProducts) and gridder.has_columns_kernel:
             from radar_processor_amd import gridding as _gr
-            if fields_per_pass >= _gr._COLUMNS_FUSE_MIN_FIELDS:      # the passes run the products epilogue: no 3-D store
+            if fields_per_pass >= _gr._COLUMNS_FUSE_MIN_FIELDS:      # (--products fused) the passes run the epilogue: no 3-D store
                 algo_bytes = gridder.columns_bytes(store_grid=False, n_keep=2, colmax=True)
                 ref_format_bytes -= fields_per_pass * 4 * n_vox
                 kernel_name = "csr_compact_rowwise_kernel (column mode, products epilogue)"
@@ -635,10 +639,10 @@ def run_rank(args):
                                                      synthetic.CONFIGS["C2"], rank, world)
             c5_extra = {"volumes_total": c5_total, "volumes_per_gpu": 8, "grid": list(shape), "mode": args.mode, **c5_extra,
                         "what": "8 seeded volumes per GPU (volume b -> rank b mod N) through batch.VolumeBatch: gridding + COLMAX/"
-                                "argmax + CAPPI@4000 m per volume, inputs resident; barrier-bracketed, max over ranks; 'auto' = "
-                                "products=PlaneProducts (epilogue of the gridding kernel where it pays), 'separate' = grids stored, "
-                                "rg_column_reduce_f32 + rg_cappi_lerp_f32 on them"}
-            for k in ("separate", "auto"):
+                                "argmax + CAPPI@4000 m per volume, inputs resident; barrier-bracketed, max over ranks; 'separate' = "
+                                "grids stored, rg_column_reduce_f32 + rg_cappi_lerp_f32 on them (the default); 'fused' = the products "
+                                "epilogue of the gridding kernel (column mode: no 3-D grid in HBM)"}
+            for k in ("separate", "fused"):
                 if k in c5_extra:
                     c5_extra[k]["mvoxel_s_all_gpus"] = round(c5_total * n_vox / (c5_extra[k]["ms_per_step"] * 1e-3) / 1e6, 1)
         except Exception as exc:

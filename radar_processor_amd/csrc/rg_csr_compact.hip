@@ -540,7 +540,10 @@ constexpr int kRowwiseChunksPerBlock = 1;   // consecutive chunks one workgroup 
 // level order and can keep the column maximum / first argmax in registers and store selected levels as planes; `out`
 // may then be null (products only: the 3-D grid is never written).  Everything between a chunk's row pointers and its
 // row sums is the same code: the same bits.
-template <typename IndT, int NF, int STRIDE, int DIAG = 0, bool COLS = false>
+// REGS: where the row sums wait for lane == row -- -1 = the field count's default (RowwiseConfig<NF>::regs), 0 = the LDS
+// array, 1 = registers.  Four fields: registers cost 99 VGPRs (4 wavefronts per SIMD), the LDS array 95 (5 wavefronts) and
+// 8 KiB of LDS per workgroup -- the launcher picks the array wherever the LDS still admits five workgroups per CU.
+template <typename IndT, int NF, int STRIDE, int DIAG = 0, bool COLS = false, int REGS = -1>
 __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
     const IndT* __restrict__ indptr, const int64_t* __restrict__ dict_ptr, const int32_t* __restrict__ dict, ChunkGrid cg,
     const float* __restrict__ packed, unsigned last_gate, float fill, int window_cap, long n_vox, float* __restrict__ out,
@@ -549,7 +552,7 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
   static_assert(NF >= 1 && NF <= 4 && (STRIDE == 1 || STRIDE == 2 || STRIDE == 4), "passes of 1-4 fields");
   using Cfg = RowwiseConfig<NF>;
   constexpr int KPRE = Cfg::kpre;
-  constexpr bool kNarrow = Cfg::narrow, kRegs = Cfg::regs;
+  constexpr bool kNarrow = Cfg::narrow, kRegs = REGS < 0 ? Cfg::regs : REGS != 0;
   // one field: the window holds (v', m) = (value, 1) of a gate, (0, 0) where it is excluded, so that a pair contributes
   // w * (v', m) -- the same float32 values as selecting on the EXCLUDED sentinel (w * 0 = +0, w * 1 = w) in two packed
   // instructions instead of a compare, two selects, a product and two adds
@@ -972,23 +975,39 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
   }
 }
 
+// Four fields, row sums in LDS instead of registers (one wavefront per SIMD more): taken when the window leaves room for five
+// workgroups per CU next to the 8 KiB array.
+constexpr long kLdsPerCu = 160 * 1024;
+inline bool rowwise_lds_rowsums(int nf, int window_cap) {
+  return nf == 4 && ((long)(window_cap + 1) * 16 + (long)kH * 64 * 4 * 8 + 512) * 5 <= kLdsPerCu;
+}
+
 template <typename IndT, int NF, int DIAG = 0>
 int launch_rowwise(int window_cap, const void* indptr, const int64_t* dict_ptr, const int32_t* dict, const ChunkGrid& cg,
                    long n_vox, const float* packed, long n_gates, float fill, float* out, hipStream_t s,
                    const PackedStream& ps, int lanes_hint, int chunks_per_block = 0) {
   constexpr int STRIDE = stride_for(NF);
   constexpr int WS = RowwiseConfig<NF>::narrow ? 3 : NF == 1 ? 2 : STRIDE;        // floats per window entry
-  constexpr long kStatic = RowwiseConfig<NF>::regs ? 16 : (long)kH * 64 * NF * 8;   // the row-sum array, if any
+  const bool lds_sums = DIAG == 0 && rowwise_lds_rowsums(NF, window_cap);
+  const long kStatic = (RowwiseConfig<NF>::regs && !lds_sums) ? 16 : (long)kH * 64 * NF * 8;   // the row-sum array, if any
   // one entry beyond window_cap: the sentinel; a smaller window only sends more chunks down the per-pair path
   const long room = (65536 - kStatic - 256) / (4 * WS) - 1;
   if (window_cap > room) window_cap = (int)room;
   const long n_chunks = chunk_count(cg);
   if (chunks_per_block <= 0) chunks_per_block = kRowwiseChunksPerBlock;      // an explicit request (tile = 2200 + n) is honoured
-  hipLaunchKernelGGL((csr_compact_rowwise_kernel<IndT, NF, STRIDE, DIAG>),
-                     dim3((unsigned)((n_chunks + chunks_per_block - 1) / chunks_per_block)), dim3(64 * kH),
-                     ((size_t)(window_cap + 1) * WS * sizeof(float) + 15) / 16 * 16, s, static_cast<const IndT*>(indptr),
-                     dict_ptr, dict, cg, packed, (unsigned)(n_gates - 1), fill, window_cap, n_vox, out, ps.rec, ps.rec_ptr,
-                     ps.w_base, lanes_hint, ps.order, (unsigned)n_chunks, chunks_per_block, RowwiseColumns());
+  const dim3 grid((unsigned)((n_chunks + chunks_per_block - 1) / chunks_per_block)), block(64 * kH);
+  const size_t lds = ((size_t)(window_cap + 1) * WS * sizeof(float) + 15) / 16 * 16;
+#define RG_ROWWISE_LAUNCH(REGS_)                                                                                              \
+  hipLaunchKernelGGL((csr_compact_rowwise_kernel<IndT, NF, STRIDE, DIAG, false, REGS_>), grid, block, lds, s,                   \
+                     static_cast<const IndT*>(indptr), dict_ptr, dict, cg, packed, (unsigned)(n_gates - 1), fill, window_cap, \
+                     n_vox, out, ps.rec, ps.rec_ptr, ps.w_base, lanes_hint, ps.order, (unsigned)n_chunks, chunks_per_block,   \
+                     RowwiseColumns())
+  if constexpr (NF == 4 && DIAG == 0) {
+    if (lds_sums) RG_ROWWISE_LAUNCH(0); else RG_ROWWISE_LAUNCH(-1);
+  } else {
+    RG_ROWWISE_LAUNCH(-1);
+  }
+#undef RG_ROWWISE_LAUNCH
   return rg::check_launch("rg_csr_compact_apply_packed_f32");
 }
 
@@ -1002,10 +1021,11 @@ static int launch_rowwise_columns_t(int window_cap, const void* indptr, const in
                                     int lanes_hint, const RowwiseColumns& cols) {
   constexpr int STRIDE = stride_for(NF);
   constexpr int WS = RowwiseConfig<NF>::narrow ? 3 : NF == 1 ? 2 : STRIDE;
+  constexpr int kRegsCols = -1;      // (four fields with the row sums in LDS: 108 instead of 111 VGPRs, the same 4 wavefronts)
   constexpr long kStatic = RowwiseConfig<NF>::regs ? 16 : (long)kH * 64 * NF * 8;
   const long room = (65536 - kStatic - 256) / (4 * WS) - 1;
   if (window_cap > room) window_cap = (int)room;
-  hipLaunchKernelGGL((csr_compact_rowwise_kernel<IndT, NF, STRIDE, 0, true>), dim3(cols.n_cols * (unsigned)cols.pieces),
+  hipLaunchKernelGGL((csr_compact_rowwise_kernel<IndT, NF, STRIDE, 0, true, kRegsCols>), dim3(cols.n_cols * (unsigned)cols.pieces),
                      dim3(64 * kH), ((size_t)(window_cap + 1) * WS * sizeof(float) + 15) / 16 * 16, s,
                      static_cast<const IndT*>(indptr), dict_ptr, dict, cg, packed, (unsigned)(n_gates - 1), fill, window_cap, n_vox,
                      out, static_cast<const rg_u32x4*>(rec), rec_ptr, w_base, lanes_hint, rec_order,

@@ -286,7 +286,8 @@ class CsrGridder:
                 + self.n_fields * (5 * self.n_gates + 4 * self.n_vox))
 
 
-_COLUMNS_FUSE_MIN_FIELDS = 4        # grid_products_device(fused=None): field-volumes per pass from which the products epilogue pays
+_COLUMNS_FUSE_MIN_FIELDS = 5        # grid_products_device(fused=None): field-volumes per pass from which the products epilogue pays
+                                    # in TIME -- more than a pass can hold: never by default (see grid_products_device)
 _COLUMNS_MIN_WORKGROUPS = 8192      # column kernel: cut columns into level pieces until the launch has about this many workgroups
 _COLUMNS_WINDOW_BYTES = 28672       # ... and each of its TWO LDS windows may take this much (64 KiB per workgroup in all)
 _PIPELINE_TILES = (128, 192, 256, 320, 384, 512)   # pairs per pipeline step the tile kernels accept (0 = their default)
@@ -409,10 +410,11 @@ def grid_products_device(geometry: GridGeometry, fields: Sequence, masks: Option
     requested by ``products``).  The planes are bit-identical to ``column_argmax`` / ``constant_altitude_ppi`` applied to
     the grid ``grid_fields_device`` returns for the same pass.
 
-    On large geometries (packed records present) a group of four field-volumes runs as ONE launch of the row-wise kernel in
-    column mode with its products epilogue: no 3-D grid is written or read back (640 MB each way per field on the bench
-    grid).  Smaller groups, other geometries and ``fused=False`` grid as usual and reduce with the separate kernels
-    (``fused=True`` forces the epilogue wherever the packed records exist: the memory-saving choice)."""
+    ``fused=True``: on large geometries (packed records present) every group of up to four field-volumes runs as ONE launch
+    of the row-wise kernel in column mode with its products epilogue -- no 3-D grid is written or read back (640 MB each
+    way per field on the bench grid), so a pass needs no grid memory at all; it takes about as long as gridding + reducing
+    separately (measured, see below).  Default (``fused=None``) and ``fused=False``: grid as usual, reduce with the separate
+    kernels."""
     from . import grid_products as gp
     torch = _native.torch_mod()
     products = products if products is not None else PlaneProducts()
@@ -446,8 +448,9 @@ def grid_products_device(geometry: GridGeometry, fields: Sequence, masks: Option
             nf = f1 - f0
             gridder = _cached_gridder(geometry, n_gates, nf, dev, compact=use_compact)
             gridder.pack(fields[f0:f1], masks[f0:f1], shared_mask)
-            # measured (profiles/r04_columns_variants_*.json): the fused pass beats gridding + separate reductions from four
-            # field-volumes per pass on (11.5 vs 12.0 ms on the bench grid) and loses below (8.2 vs 8.1 ms for one field)
+            # measured (profiles/r04_columns_variants_*.json, r04_nf4_lds_rowsums.json): walking columns costs what the store it
+            # saves costs -- 8.2 vs 8.1 ms for one field, 10.7 vs 10.5 for three, 11.4 vs 11.2 for four on the bench grid --
+            # so the epilogue is the MEMORY-saving choice (no F x 640 MB of grid) and is taken on request, not by default
             run_fused = (gridder.has_columns_kernel and (nf >= _COLUMNS_FUSE_MIN_FIELDS if fused is None else bool(fused)))
             if run_fused:
                 cmax = torch.empty((nf, ny, nx), dtype=torch.float32, device=dev) if products.colmax else None

@@ -143,7 +143,7 @@ def test_two_rank_line_carries_per_rank_kernel_times_and_the_config5_side_measur
     assert len(per_rank) == 2 and all(0 < v < 100 for v in per_rank)
     c5 = line["extras"]["c5"]
     assert c5["volumes_total"] == 16 and c5["volumes_per_gpu"] == 8
-    for mode in ("separate", "auto"):
+    for mode in ("separate", "fused"):
         assert c5[mode]["ms_per_step"] > 0 and c5[mode]["passes_per_step"] == 2 and c5[mode]["mvoxel_s_all_gpus"] > 0
     # ... and the products mode of the config-5 line itself is recorded
     one = _run_bench(["--gpus", "1", "--config", "C5", "--c5-grid", "C2", "--volumes-per-gpu", "4", "--products", "fused"])
