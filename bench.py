@@ -555,6 +555,7 @@ def run_rank(args):
         + (f": {n_pairs:,} pairs ({n_pairs / n_vox:.1f}/voxel), {algo_bytes / 1e9:.2f} GB algorithmic per launch" if n_pairs else ""))
 
     events = []                                   # (start, end) per gridding launch inside the timed region
+    kernel_mode = None
 
     if c5:
         vb = batch.VolumeBatch(batch_geometry, field_names, device=dev)
@@ -573,7 +574,7 @@ def run_rank(args):
             if fields_per_pass >= _gr._COLUMNS_FUSE_MIN_FIELDS:      # (--products fused) the passes run the epilogue: no 3-D store
                 algo_bytes = gridder.columns_bytes(store_grid=False, n_keep=2, colmax=True)
                 ref_format_bytes -= fields_per_pass * 4 * n_vox
-                kernel_name = "csr_compact_rowwise_kernel (column mode, products epilogue)"
+                kernel_mode = "column mode, products epilogue (no 3-D store)"
 
         def step(timed=False):
             return vb.grid_shard(dev_volumes, products=c5_products, rank=rank, world_size=world,
@@ -748,7 +749,7 @@ def run_rank(args):
         compact_on = args.mode == "csr" and gridder.compact is not None
         rowwise_on = compact_on and kernel_name == "csr_compact_rowwise_kernel"
         workload_key = (f"{args.config}/{'csr_rowwise' if rowwise_on else 'csr_compact' if compact_on else args.mode}"
-                        f"/F{n_f}/B{n_vol}")
+                        f"{'_products' if kernel_mode else ''}/F{n_f}/B{n_vol}")
         traffic, traffic_source = pmc_traffic(workload_key)
         result = {
             "metric": "Mvoxels/s gridded (+ achieved HBM GB/s in roofline)",
@@ -777,6 +778,7 @@ def run_rank(args):
             "roofline": {
                 "bound": "hbm" if args.mode == "csr" else "valu (reported against hbm)",
                 "kernel": kernel_name,
+                "kernel_mode": kernel_mode,
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

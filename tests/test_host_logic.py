@@ -307,9 +307,9 @@ class TestNativeLibrary:
         if nm.returncode == 0:       # host-side kernel stubs carry the template arguments
             rows = [l for l in nm.stdout.splitlines() if "csr_compact_rowwise_kernel<" in l]
             assert rows, "row-wise kernel not found in the symbol table"
-            for l in rows:           # <IndT, NF, STRIDE, DIAG, COLS>: DIAG must be 0 everywhere
+            for l in rows:           # <IndT, NF, STRIDE, DIAG, COLS, REGS>: DIAG must be 0 everywhere
                 args = l[l.index("csr_compact_rowwise_kernel<") + len("csr_compact_rowwise_kernel<"):].split(">(")[0].split(",")
-                assert len(args) == 5 and args[3].strip() == "0", l
+                assert len(args) == 6 and args[3].strip() == "0", l
 
     def test_ensure_built_rebuilds_a_stale_library(self, tmp_path, monkeypatch):
         """ensure_built() compiles when the library is missing AND when it was built from other sources or headers than

@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 OUT=gpurun_out/prof_${TAG}
 rm -rf "$OUT"
 mkdir -p "$OUT"
-ARGS="--steps 5 --warmup 1 --no-cpu-baseline $*"
+ARGS="--steps 5 --warmup 1 --no-cpu-baseline --no-c5-extra $*"
 python3 -m radar_processor_amd.build > "$OUT/build.log" 2>&1 || exit 1   # nothing may compile (= exec hipcc) under the profiler
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py $ARGS > "$OUT/trace_bench.json" 2> "$OUT/trace.log" || exit 1
 echo "trace done"
