@@ -748,3 +748,48 @@ def test_metric_fused_gridder_and_products(metric):
         np.testing.assert_array_equal(arg[iy].cpu().numpy(), oracle.column_argmax(rows, 0, nz - 1)[0])
     assert bool((cap[both] >= torch.minimum(lo, hi)[both] - 1e-4).all())
     assert bool((cap[both] <= torch.maximum(lo, hi)[both] + 1e-4).all())
+
+
+def test_metric_column_mode_grid_and_products_only(metric):
+    """rg_csr_compact_apply_columns_f32 on the metric workload (640 000 chunks, int64 row pointers, offsets past 2^31): with
+    the 3-D store its grid is the row-wise kernel's, bit for bit, on every voxel; products only -- nothing but planes is
+    written -- COLMAX / first argmax over an altitude window and the two levels of the 4000 m CAPPI equal
+    rg_column_reduce_f32 / the grid's own levels on the whole 2000 x 2000 plane, and the oracle (products.py:361-412,
+    462-490 restated) on whole rows of the 40 x 2000 x 2000 grid; the fused API returns the same planes."""
+    from radar_processor_amd.gridding import CsrGridder
+    rg, torch, geom, dev, cfg = (metric[k] for k in ("rg", "torch", "geom", "dev", "cfg"))
+    _, k1c = _metric_grids(metric)
+    nz, ny, nx = cfg["grid_shape"]
+    f, m = metric["f"], metric["m"]
+    g = CsrGridder(geom, f.numel(), 1, device=dev, compact=True)
+    assert g.has_columns_kernel
+    g.pack([f], [m])
+    col = torch.full_like(k1c, -7.0)
+    g.apply_columns(out=col)
+    assert bool(torch.equal(col.view(torch.int32), k1c.view(torch.int32)))
+    del col
+    grid = k1c.view(nz, ny, nx)
+    plan = oracle.cappi_plan(cfg["grid_limits"][0], nz, 4000.0)
+    assert plan[0] == "lerp"
+    lo, hi = oracle.column_range(nz, z_min_alt=1000.0, z_max_alt=12000.0, z_limits=cfg["grid_limits"][0])
+    cmax = torch.full((1, ny, nx), -7.0, dtype=torch.float32, device=dev)
+    carg = torch.full((1, ny, nx), -7, dtype=torch.int32, device=dev)
+    planes = torch.full((1, 2, ny, nx), -7.0, dtype=torch.float32, device=dev)
+    for pieces in (1, 3):
+        g.apply_columns(out=None, level_planes=planes, keep_lo=plan[1], col_max=cmax, col_arg=carg, col_window=(lo, hi),
+                        z_pieces=pieces)
+        want_max, want_arg = rg.column_argmax(grid, z_min_idx=lo, z_max_idx=hi)
+        assert bool(torch.equal(cmax[0].view(torch.int32), want_max.view(torch.int32))) and bool(torch.equal(carg[0], want_arg))
+        assert bool(torch.equal(planes[0].view(torch.int32), grid[plan[1]:plan[1] + 2].contiguous().view(torch.int32)))
+    for iy in (0, 1000, 1999):                                       # the oracle on whole y-rows, bit for bit
+        rows = grid[:, iy, :].cpu().numpy()[:, None, :]
+        np.testing.assert_array_equal(cmax[0, iy].cpu().numpy(), oracle.column_max(rows, lo, hi)[0])
+        np.testing.assert_array_equal(carg[0, iy].cpu().numpy(), oracle.column_argmax(rows, lo, hi)[0])
+    rec = rg.grid_products_device(geom, [f], [m], products=rg.PlaneProducts(cappi=(4000.0,), z_min_alt=1000.0, z_max_alt=12000.0),
+                                  fused=True)[0]
+    assert bool(torch.equal(rec["colmax"].view(torch.int32), cmax[0].view(torch.int32))) and bool(torch.equal(rec["argmax"], carg[0]))
+    cap = rg.constant_altitude_ppi(grid, geom, 4000.0)
+    assert bool(torch.equal(rec["cappi"][4000.0].view(torch.int32), cap.view(torch.int32)))
+    for iy in (3, 1234):
+        rows = grid[:, iy, :].cpu().numpy()[:, None, :]
+        np.testing.assert_array_equal(rec["cappi"][4000.0][iy].cpu().numpy(), oracle.cappi(rows, cfg["grid_limits"][0], 4000.0)[0])
