@@ -359,53 +359,73 @@ def gather_per_rank(dist, backend, dev, value: float):
 def c5_side_measurement(args, rg, batch, synthetic, torch, dist, dev, geom_or_search, grid_geom, cfg_gates, rank, world, steps=3):
     """north_star's batch figure next to ANY bench line: 8 seeded volumes per GPU (volume b -> rank b mod N, seed b; 64 volumes
     on 8 GPUs) sharing one geometry, through batch.VolumeBatch, products = COLMAX + argmax + CAPPI@4000 m per volume;
-    barrier-bracketed, max over ranks.  Both ways of producing the planes are timed (epilogue of the gridding kernel / separate
-    kernels on stored grids)."""
+    barrier-bracketed, max over ranks.  Both ways of producing the planes are timed (separate kernels on stored grids / the
+    epilogue of the gridding kernel).  Collective-safe: a rank whose part fails keeps meeting the others in every barrier and
+    all-reduce, and the failure is reported in the result instead of hanging or killing the bench line."""
+    from radar_processor_amd import gridding as _gr
+    from radar_processor_amd.gridding import PlaneProducts
     per_gpu = 8
     total = per_gpu * world
-    mine = batch.shard_indices(total, rank, world)
-    vols = [None] * total
-    for b in mine:
-        v = synthetic.make_volume(cfg_gates["n_elev"], cfg_gates["n_az"], cfg_gates["n_gates"], seed=b, fields=("DBZH",))
-        vols[b] = {"DBZH": (torch.from_numpy(np.ascontiguousarray(np.ma.getdata(v.fields["DBZH"]))).to(dev),
-                            torch.from_numpy(np.ma.getmaskarray(v.fields["DBZH"]).astype(np.uint8)).to(dev))}
-    vb = batch.VolumeBatch(geom_or_search, ("DBZH",), device=dev)
+    err = None
+    vols, vb = [None] * total, None
+    try:
+        for b in batch.shard_indices(total, rank, world):
+            v = synthetic.make_volume(cfg_gates["n_elev"], cfg_gates["n_az"], cfg_gates["n_gates"], seed=b, fields=("DBZH",))
+            vols[b] = {"DBZH": (torch.from_numpy(np.ascontiguousarray(np.ma.getdata(v.fields["DBZH"]))).to(dev),
+                                torch.from_numpy(np.ma.getmaskarray(v.fields["DBZH"]).astype(np.uint8)).to(dev))}
+        vb = batch.VolumeBatch(geom_or_search, ("DBZH",), device=dev)
+    except Exception as exc:
+        err = repr(exc)
 
     def separate(g):
         return [(rg.column_argmax(g[k]), rg.constant_altitude_ppi(g[k], grid_geom, 4000.0)) for k in range(g.shape[0])]
-    from radar_processor_amd.gridding import PlaneProducts
-    spec = PlaneProducts(colmax=True, argmax=True, cappi=(4000.0,))
-    from radar_processor_amd import gridding as _gr
-    modes = {"separate": separate, "fused": spec}
+    modes = {"separate": separate, "fused": PlaneProducts(colmax=True, argmax=True, cappi=(4000.0,))}
     out = {}
     default_min = _gr._COLUMNS_FUSE_MIN_FIELDS
+
+    def meet():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
     for name, products in modes.items():
-        if name == "fused" and vb.fused:
+        if name == "fused" and args.mode != "csr":
             continue                                    # the CSR-free gridder has no epilogue
         _gr._COLUMNS_FUSE_MIN_FIELDS = 1 if name == "fused" else default_min     # 'fused': the epilogue for every pass
         events = []
 
         def one(timed=False):
             return vb.grid_shard(vols, products=products, rank=rank, world_size=world, events=events if timed else None)
-        one()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        try:
+            if err is None:
+                one()
+        except Exception as exc:
+            err = repr(exc)
+        meet()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            one(True)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        try:
+            if err is None:
+                for _ in range(steps):
+                    one(True)
+        except Exception as exc:
+            err = repr(exc)
+        meet()
         dt = (time.perf_counter() - t0) / steps
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        pass_ms = [a.elapsed_time(b) for a, b in events]
+        pass_ms = [a.elapsed_time(b) for a, b in events] if err is None else []
         out[name] = {"ms_per_step": round(dt * 1e3, 3), "pass_ms_median": round(float(np.median(pass_ms)), 3) if pass_ms else None,
                      "passes_per_step": len(pass_ms) / steps}
     _gr._COLUMNS_FUSE_MIN_FIELDS = default_min
+    bad = 0.0 if err is None else 1.0
+    if world > 1:
+        t = torch.tensor([bad], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        bad = float(t.item())
+    if bad:
+        return {"failed": err or "another rank failed"}, total
     return out, total
 
 
@@ -644,13 +664,11 @@ def run_rank(args):
                                 "grids stored, rg_column_reduce_f32 + rg_cappi_lerp_f32 on them (the default); 'fused' = the products "
                                 "epilogue of the gridding kernel (column mode: no 3-D grid in HBM)"}
             for k in ("separate", "fused"):
-                if k in c5_extra:
+                if k in c5_extra and isinstance(c5_extra[k], dict):
                     c5_extra[k]["mvoxel_s_all_gpus"] = round(c5_total * n_vox / (c5_extra[k]["ms_per_step"] * 1e-3) / 1e6, 1)
-        except Exception as exc:
+        except Exception as exc:                   # (the measurement itself is collective-safe; this is the bookkeeping)
             log(f"rank {rank}: extras.c5 failed: {exc!r}")
             c5_extra = {"failed": repr(exc)}
-            if world > 1:
-                raise                              # ranks must not diverge inside a collective
 
     # ---- the grid that was just timed is checked, outside the timed region (rank 0) ------------------------------
     # the compact kernel against the reference-format kernel on the same inputs, every voxel: the row-wise kernel to
