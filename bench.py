@@ -165,7 +165,10 @@ def spawn_ranks(args, argv=None, poll_s: float = 0.2, grace_s: float = 10.0) -> 
         log(f"rank exit codes: {[p.returncode for p in procs]}")
         return 1
     reader.join(timeout=30)
-    sys.stdout.write(b"".join(chunks).decode())
+    # rank 0's stdout carries the ONE JSON line -- and, with the gloo rehearsal backend, a "[Gloo] Rank 0 is connected ..." line
+    # that library prints there: only the JSON goes on, the rest to stderr
+    for line in b"".join(chunks).decode().splitlines():
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
     return 0
 
