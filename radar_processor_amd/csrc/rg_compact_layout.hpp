@@ -152,7 +152,11 @@ template <> struct RowwiseConfig<2> { static constexpr int kpre = 3, target = 4;
 #undef RG_ROWWISE_REGS3
 #define RG_ROWWISE_REGS3 true
 #endif
-template <> struct RowwiseConfig<3> { static constexpr int kpre = RG_ROWWISE_KPRE3, target = RG_ROWWISE_TARGET3; static constexpr bool narrow = true, regs = RG_ROWWISE_REGS3; };
+#if !defined(RG_EXPERIMENTS) || !defined(RG_ROWWISE_NARROW3)
+#undef RG_ROWWISE_NARROW3
+#define RG_ROWWISE_NARROW3 true
+#endif
+template <> struct RowwiseConfig<3> { static constexpr int kpre = RG_ROWWISE_KPRE3, target = RG_ROWWISE_TARGET3; static constexpr bool narrow = RG_ROWWISE_NARROW3, regs = RG_ROWWISE_REGS3; };
 template <> struct RowwiseConfig<4> { static constexpr int kpre = 3, target = 8; static constexpr bool narrow = false, regs = true; };
 
 
