@@ -365,7 +365,6 @@ def c5_side_measurement(args, rg, batch, synthetic, torch, dist, dev, geom_or_se
     barrier-bracketed, max over ranks.  Both ways of producing the planes are timed (separate kernels on stored grids / the
     epilogue of the gridding kernel).  Collective-safe: a rank whose part fails keeps meeting the others in every barrier and
     all-reduce, and the failure is reported in the result instead of hanging or killing the bench line."""
-    from radar_processor_amd import gridding as _gr
     from radar_processor_amd.gridding import PlaneProducts
     per_gpu = 8
     total = per_gpu * world
@@ -382,9 +381,8 @@ def c5_side_measurement(args, rg, batch, synthetic, torch, dist, dev, geom_or_se
 
     def separate(g):
         return [(rg.column_argmax(g[k]), rg.constant_altitude_ppi(g[k], grid_geom, 4000.0)) for k in range(g.shape[0])]
-    modes = {"separate": separate, "fused": PlaneProducts(colmax=True, argmax=True, cappi=(4000.0,))}
+    modes = {"separate": separate, "fused": PlaneProducts(colmax=True, argmax=True, cappi=(4000.0,), fused=True)}
     out = {}
-    default_min = _gr._COLUMNS_FUSE_MIN_FIELDS
 
     def meet():
         torch.cuda.synchronize()
@@ -394,7 +392,6 @@ def c5_side_measurement(args, rg, batch, synthetic, torch, dist, dev, geom_or_se
     for name, products in modes.items():
         if name == "fused" and args.mode != "csr":
             continue                                    # the CSR-free gridder has no epilogue
-        _gr._COLUMNS_FUSE_MIN_FIELDS = 1 if name == "fused" else default_min     # 'fused': the epilogue for every pass
         events = []
 
         def one(timed=False):
@@ -421,7 +418,6 @@ def c5_side_measurement(args, rg, batch, synthetic, torch, dist, dev, geom_or_se
         pass_ms = [a.elapsed_time(b) for a, b in events] if err is None else []
         out[name] = {"ms_per_step": round(dt * 1e3, 3), "pass_ms_median": round(float(np.median(pass_ms)), 3) if pass_ms else None,
                      "passes_per_step": len(pass_ms) / steps}
-    _gr._COLUMNS_FUSE_MIN_FIELDS = default_min
     bad = 0.0 if err is None else 1.0
     if world > 1:
         t = torch.tensor([bad], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
@@ -587,14 +583,11 @@ def run_rank(args):
         def reducer(g):
             return [(rg.column_argmax(g[k]), rg.constant_altitude_ppi(g[k], geom, 4000.0)) for k in range(g.shape[0])]
         # the same planes either way (tests/test_gpu_columns.py, test_gpu_batch.py): COLMAX + argmax + CAPPI@4000 m per volume
-        c5_products = reducer if (args.products == "separate" or args.mode != "csr") else PlaneProducts(cappi=(4000.0,))
-        if args.products == "fused" and args.mode == "csr":
-            from radar_processor_amd import gridding as _gr
-            _gr._COLUMNS_FUSE_MIN_FIELDS = 1                 # force the epilogue for every pass
+        c5_products = (reducer if (args.products == "separate" or args.mode != "csr")
+                       else PlaneProducts(cappi=(4000.0,), fused=True if args.products == "fused" else None))
 
         if args.mode == "csr" and isinstance(c5_products, PlaneProducts) and gridder.has_columns_kernel:
-            from radar_processor_amd import gridding as _gr
-            if fields_per_pass >= _gr._COLUMNS_FUSE_MIN_FIELDS:      # (--products fused) the passes run the epilogue: no 3-D store
+            if c5_products.fused:                        # (--products fused) the passes run the epilogue: no 3-D store
                 algo_bytes = gridder.columns_bytes(store_grid=False, n_keep=2, colmax=True)
                 ref_format_bytes -= fields_per_pass * 4 * n_vox
                 kernel_mode = "column mode, products epilogue (no 3-D store)"

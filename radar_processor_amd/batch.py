@@ -187,7 +187,7 @@ class VolumeBatch:
         """Returns ``{volume index: grids [F, nz, ny, nx]}`` -- or ``{index: products(grids)}`` when a reducer is
         given, so that only 2-D planes outlive the pass.  ``products`` may also be a :class:`gridding.PlaneProducts`
         (column maximum / argmax / CAPPIs): the result is then ``{index: [one dict of planes per field]}`` and, on the CSR
-        path of a large geometry, the pass runs the column-persistent kernel with its products epilogue -- the 3-D grids
+        path of a large geometry and on request, the pass runs the gridding kernel's column mode with its products epilogue -- the 3-D grids
         are neither written nor read back (``gridding.grid_products_device``).  ``volumes`` is indexed by the GLOBAL volume number; only this
         rank's entries (``shard_indices``) are touched, the others may be ``None``.  ``events``: optional list that
         receives one ``(start, end)`` pair of stream events per gridding pass (mask fold + gridding kernel), for

@@ -184,10 +184,10 @@ class CsrGridder:
             float(np.float32(fill_value)), _native.ptr(out), self.tile if self.tile in _PIPELINE_TILES else 0,
             _native.stream_ptr()), "rg_csr_apply_f32")
 
-    # ---- column-persistent kernel (rg_csr_compact_apply_columns_f32) ------------------------------------------------
+    # ---- column mode of the row-wise kernel (rg_csr_compact_apply_columns_f32) ----------------------------------------
     @property
     def has_columns_kernel(self) -> bool:
-        """The column-persistent kernel reads the packed records: 1-4 fields, codable weights."""
+        """The column mode of the row-wise kernel reads the packed records: 1-4 fields, codable weights."""
         return self.compact is not None and self.packed_stream
 
     def _column_plan(self, z_pieces: int):
@@ -224,14 +224,14 @@ class CsrGridder:
 
     def apply_columns(self, out=None, fill_value: float = np.nan, level_planes=None, keep_lo: int = 0, col_max=None,
                       col_arg=None, col_window=None, z_pieces: int = 0, lanes_hint: int = 0, ordered: bool = True) -> None:
-        """One pass of ``rg_csr_compact_apply_columns_f32`` over the packed records (workgroups persistent over a column of
-        chunks, the next chunk's window prefetched): ``out`` ``[F, n_vox]`` receives the same bits as :meth:`apply` with the
+        """One pass of ``rg_csr_compact_apply_columns_f32`` over the packed records (the row-wise kernel with every workgroup
+        walking the levels of one column of chunks): ``out`` ``[F, n_vox]`` receives the same bits as :meth:`apply` with the
         row-wise kernel, or is ``None`` when only 2-D products are wanted -- ``level_planes`` ``[F, n_keep, ny, nx]``
         (planes ``keep_lo ..`` of every grid), ``col_max`` / ``col_arg`` ``[F, ny, nx]`` (``column_argmax`` over the level
         window ``col_window = (lo, hi)``, default all levels)."""
         torch = _native.torch_mod()
         if not self.has_columns_kernel:
-            raise _native.NativeError("the column-persistent kernel needs the packed records (1-4 fields, codable weights)")
+            raise _native.NativeError("the column mode needs the packed records (1-4 fields, codable weights)")
         csr, c = self.csr, self.compact
         nz, ny, nx = self.grid_shape
         n_keep = 0 if level_planes is None else int(level_planes.shape[1])
@@ -245,7 +245,7 @@ class CsrGridder:
             ws = getattr(self, "_columns_ws", None)
             if ws is None or ws.numel() < nbytes:
                 ws = self._columns_ws = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
-        window = min(self.window, c.window_for(self.n_fields, _COLUMNS_WINDOW_BYTES))
+        window = self.window
         _native.check(self.lib.rg_csr_compact_apply_columns_f32(
             _native.ptr(csr.indptr), int(csr.is_i64), _native.ptr(c.rec), _native.ptr(c.rec_ptr), c.rec_order, c.w_base,
             _native.ptr(c.dict_ptr), _native.ptr(c.dict), self.n_vox, csr.n_pairs, nx, ny, _native.ptr(self.packed),
@@ -289,7 +289,6 @@ class CsrGridder:
 _COLUMNS_FUSE_MIN_FIELDS = 5        # grid_products_device(fused=None): field-volumes per pass from which the products epilogue pays
                                     # in TIME -- more than a pass can hold: never by default (see grid_products_device)
 _COLUMNS_MIN_WORKGROUPS = 8192      # column kernel: cut columns into level pieces until the launch has about this many workgroups
-_COLUMNS_WINDOW_BYTES = 28672       # ... and each of its TWO LDS windows may take this much (64 KiB per workgroup in all)
 _PIPELINE_TILES = (128, 192, 256, 320, 384, 512)   # pairs per pipeline step the tile kernels accept (0 = their default)
 _COMPACT_MIN_PAIRS = 50_000_000     # below this a pass takes well under a millisecond either way
 _COMPACT_MAX_WINDOW_BYTES = 24576  # LDS window beyond which the standard kernel is the faster one (CsrGridder.__init__)
@@ -388,12 +387,15 @@ class PlaneProducts:
     ``batch.VolumeBatch.grid_shard(products=PlaneProducts(...))``): the column maximum over a level window
     (``radar_grid/products.py:420-490``; same window arguments as ``column_max``), optionally the level that attains it
     (``column_argmax``), and CAPPIs at the given altitudes (``products.py:317-415``).  With these and nothing else wanted,
-    the 3-D grid never has to exist in HBM: the column-persistent gridding kernel keeps the running maximum in registers
+    the 3-D grid never has to exist in HBM: the gridding kernel, walking grid columns, keeps the running maximum in registers
     and stores only the levels the CAPPIs blend."""
 
     def __init__(self, colmax: bool = True, argmax: bool = True, cappi: Sequence[float] = (), interpolation: str = "linear",
                  z_min_idx: Optional[int] = None, z_max_idx: Optional[int] = None, z_min_alt: Optional[float] = None,
-                 z_max_alt: Optional[float] = None):
+                 z_max_alt: Optional[float] = None, fused: Optional[bool] = None):
+        """``fused``: ``True`` = take the planes out of the gridding kernel (no 3-D grid in HBM: the memory-saving way),
+        ``False`` = grid, then reduce with the separate kernels, ``None`` = whichever the build measured faster (the same
+        planes either way, bit for bit)."""
         if interpolation not in ("linear", "nearest"):
             raise ValueError(f"Unknown interpolation method: {interpolation}")
         self.colmax = bool(colmax or argmax)
@@ -401,6 +403,7 @@ class PlaneProducts:
         self.cappi = tuple(float(a) for a in cappi)
         self.interpolation = interpolation
         self.window = (z_min_idx, z_max_idx, z_min_alt, z_max_alt)
+        self.fused = fused
 
 
 def grid_products_device(geometry: GridGeometry, fields: Sequence, masks: Optional[Sequence] = None, shared_mask=None,
@@ -418,6 +421,8 @@ def grid_products_device(geometry: GridGeometry, fields: Sequence, masks: Option
     from . import grid_products as gp
     torch = _native.torch_mod()
     products = products if products is not None else PlaneProducts()
+    if fused is None:
+        fused = products.fused
     n_fields = len(fields)
     if n_fields == 0:
         raise ValueError("no fields to grid")

@@ -1,4 +1,4 @@
-"""The column-persistent row-wise kernel (rg_csr_compact_apply_columns_f32, csrc/rg_csr_columns.hip) through the C ABI:
+"""The column mode of the row-wise kernel (rg_csr_compact_apply_columns_f32, csrc/rg_csr_columns.hip) through the C ABI:
 
  * its 3-D grids are the same BITS as the one-chunk-per-workgroup row-wise kernel's (and therefore as
    oracle.csr_apply_rowwise_order's) -- on the reference's CSRs (tests/golden), on hand-made CSRs with ragged shapes, empty
