@@ -360,6 +360,52 @@ class TestNativeLibrary:
         assert _native.load_library(require_device=False).rg_version() == _native.ABI_VERSION
         assert "RG_LIBRARY" not in open(_native.__file__).read().replace("no environment override", "")
 
+    def test_columns_entry_point_validates_before_touching_the_device(self):
+        """rg_csr_compact_apply_columns_f32 / rg_csr_columns_workspace_bytes: argument checks only (nothing is launched)."""
+        lib = rg.load_library(require_device=False)
+        p = 1 << 12
+
+        def call(**kw):
+            a = dict(indptr=p, is64=0, rec=p, rec_ptr=p, order=_native.RG_REC_ORDER_DISPATCH, w_base=120 << 23, dict_ptr=p, dict=p,
+                     n_vox=2 * 4 * 64, n_pairs=0, nx=64, ny=4, packed=p, nf=3, stride=4, n_gates=100, fill=0.0, out=p, planes=None,
+                     keep_lo=0, n_keep=0, cmax=None, carg=None, lo=0, hi=1, window=256, pieces=1, wg_order=None, ws=None,
+                     ws_bytes=0, hint=0)
+            a.update(kw)
+            return lib.rg_csr_compact_apply_columns_f32(*a.values(), None)
+        assert call(out=None) == _native.RG_EINVAL and b"nothing to produce" in lib.rg_last_error()
+        assert call(pieces=3) == _native.RG_EINVAL and call(pieces=0) == _native.RG_EINVAL          # 2 planes
+        assert call(planes=p, keep_lo=1, n_keep=2) == _native.RG_EINVAL
+        assert call(carg=p) == _native.RG_EINVAL
+        assert call(cmax=p, lo=1, hi=0) == _native.RG_EINVAL and call(cmax=p, hi=2) == _native.RG_EINVAL
+        assert call(cmax=p, pieces=2) == _native.RG_EWORKSPACE and b"workspace" in lib.rg_last_error()
+        assert call(hint=3) == _native.RG_EINVAL and call(hint=1000) == _native.RG_EINVAL     # no experiment variants here
+        assert call(nf=5, stride=8) == _native.RG_EUNSUPPORTED and call(stride=2) == _native.RG_EINVAL
+        assert call(w_base=1) == _native.RG_EINVAL and call(order=7) == _native.RG_EINVAL
+        assert call(n_vox=100) == _native.RG_EINVAL                                             # not planes x lines x rows
+        assert call(packed=p + 4) == _native.RG_EALIGN
+        assert lib.rg_csr_columns_workspace_bytes(2000, 2000, 4, 3) == 3 * 4 * 4_000_000 * 8
+        assert lib.rg_csr_columns_workspace_bytes(4, 64, 3, 1) == 0
+        assert lib.rg_csr_columns_workspace_bytes(4, 64, 5, 2) == _native.RG_EINVAL
+
+    def test_plane_products_request_and_layout_digest(self):
+        """PlaneProducts validates like the reference's functions do; the sidecar key changes with the CSR and with the
+        chunk layout constants, not with anything else."""
+        from radar_processor_amd import grid_geometry
+        with pytest.raises(ValueError, match="Unknown interpolation method"):
+            rg.PlaneProducts(cappi=(1000.0,), interpolation="cubic")
+        spec = rg.PlaneProducts(colmax=False, argmax=True, cappi=[2500, 4000.0], z_min_alt=1000.0, fused=True)
+        assert spec.colmax and spec.argmax and spec.cappi == (2500.0, 4000.0) and spec.window == (None, None, 1000.0, None)
+        assert spec.fused is True and rg.PlaneProducts().fused is None
+        g = rg.GridGeometry((1, 2, 2), ((0.0, 0.0), (0.0, 1.0), (0.0, 1.0)), np.array([0, 1, 2, 2, 3], dtype=np.int32),
+                            np.array([0, 1, 2], dtype=np.int32), np.array([1.0, 0.5, 0.25], dtype=np.float32), toa=17000.0)
+        key = grid_geometry._reference_arrays_digest(g)
+        assert key == grid_geometry._reference_arrays_digest(g) and len(key) == 64
+        g2 = rg.GridGeometry(g.grid_shape, ((0.0, 9.0), (0.0, 1.0), (0.0, 1.0)), g.indptr.copy(), g.gate_indices.copy(),
+                             g.weights.copy(), toa=1.0)
+        assert grid_geometry._reference_arrays_digest(g2) == key          # limits / toa are not what the copy is derived from
+        g2.weights = np.array([1.0, 0.5, 0.125], dtype=np.float32)
+        assert grid_geometry._reference_arrays_digest(g2) != key
+
     @pytest.mark.skipif(not _no_gpu(), reason="only meaningful on a box without a GPU")
     def test_no_cpu_fallback(self, geometry):
         """Without a HIP device the product path raises instead of computing on the CPU."""
@@ -380,6 +426,9 @@ class TestNativeLibrary:
             rg.apply_colormap_to_array(plane.filled(np.nan), np.array([[0, 0, 0], [1, 1, 1]], dtype=float), 0.0, 1.0)
         with pytest.raises(rg.NativeUnavailable):
             rg.GridFilter().apply_below(plane.filled(np.nan), 15.0)
+        import torch
+        with pytest.raises(rg.NativeUnavailable):                       # the products-only path has no CPU route either
+            rg.grid_products_device(geometry, [torch.zeros(240)], products=rg.PlaneProducts(cappi=(1500.0,)))
         with pytest.raises(rg.NativeUnavailable):
             rg.compute_grid_geometry(np.zeros(4, np.float32), np.zeros(4, np.float32), np.zeros(4, np.float32), (1, 2, 2),
                                      ((0.0, 0.0), (0.0, 1.0), (0.0, 1.0)), ".", layout="compact")
