@@ -632,7 +632,10 @@ def run_rank(args):
         step(True)
     barrier()
     elapsed = time.perf_counter() - t0
+    per_rank_ms_per_step = [round(elapsed / args.steps * 1e3, 4)]
     if world > 1:
+        # every rank's own wall time for the K steps (between the same two barriers), then the max the contract asks for
+        per_rank_ms_per_step = gather_per_rank(dist, args.dist_backend, dev, elapsed / args.steps * 1e3)
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -779,6 +782,7 @@ def run_rank(args):
             "dtype": "f32",
             "data": "synthetic",
             "per_rank_kernel_ms": per_rank_kernel_ms,
+            "per_rank_ms_per_step": per_rank_ms_per_step,
             "config": {"workload": workload, "key": workload_key, "gates": n_gates, "voxels": n_vox,
                        "pairs": n_pairs, "fields_per_pass": fields_per_pass, "volumes_total": total_vol,
                        "ranks_seen_by_process_group": dist.get_world_size() if world > 1 else 1,

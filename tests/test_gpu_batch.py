@@ -141,6 +141,8 @@ def test_two_rank_line_carries_per_rank_kernel_times_and_the_config5_side_measur
     assert line["n_gpus"] == 2 and line["config"]["ranks_seen_by_process_group"] == 2
     per_rank = line["per_rank_kernel_ms"]
     assert len(per_rank) == 2 and all(0 < v < 100 for v in per_rank)
+    steps = line["per_rank_ms_per_step"]
+    assert len(steps) == 2 and all(0 < v <= line["ms_per_step"] * 1.001 for v in steps)     # value is priced on the slowest rank
     c5 = line["extras"]["c5"]
     assert c5["volumes_total"] == 16 and c5["volumes_per_gpu"] == 8
     for mode in ("separate", "fused"):
