@@ -54,6 +54,10 @@ def _stale(target: str, deps: List[str]) -> bool:
 def build(force: bool = False, verbose: bool = True) -> str:
     """Compile every HIP source for gfx950 and link the shared library. Returns its path."""
     hipcc = _hipcc()
+    if not force and os.path.exists(STAMP_PATH):
+        with open(STAMP_PATH) as f:             # contents changed behind unchanged time stamps (a restored file): rebuild all
+            force = f.read().strip() != source_digest() and all(
+                not _stale(os.path.join(CSRC, src.replace(".hip", ".o")), sources_and_headers()) for src, _ in SOURCES)
     headers = ([os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".hpp")]
                + [os.path.join(INCLUDE, "radargrid_hip.h")])
     common = ["-std=c++17", "-O3", f"--offload-arch={ARCH}", "-fPIC",
