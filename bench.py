@@ -68,6 +68,10 @@ def parse_args(argv=None):
                          "volume, then rg_column_reduce_f32 / rg_cappi_lerp_f32 on the stored grids; fused = the gridding kernel's "
                          "products epilogue (column mode, no 3-D grid in HBM: the memory-saving way, about as fast); auto = what "
                          "batch.VolumeBatch does for products=PlaneProducts (separate: measured at least as fast)")
+    ap.add_argument("--settle-tries", type=int, default=3,
+                    help="csr mode, packed records: placements of the record array tried during the (untimed) geometry build -- the "
+                         "fastest under a 3-launch probe of the gridding kernel is kept (CsrGridder.settle_records); 1 = off. "
+                         "Reported in config.records_settled")
     ap.add_argument("--no-c5-extra", action="store_true",
                     help="skip the extras.c5 side measurement (8 seeded volumes per GPU through batch.VolumeBatch after the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -547,6 +551,16 @@ def run_rank(args):
             want_compact = free_b > 3.2 * geom.n_pairs() + (8 << 30)
         gridder = CsrGridder(geom, n_gates, fields_per_pass, device=dev, compact=want_compact)
         n_pairs = gridder.csr.n_pairs
+        settled = None
+        torch.cuda.synchronize()
+        t_built = time.perf_counter() - t0                       # the geometry itself; what follows is optional tuning
+        if gridder.compact is not None and gridder.packed_stream and args.settle_tries > 1 and not args.tile_kernel:
+            gridder.pack(fields_d[:fields_per_pass] if len(fields_d) >= fields_per_pass else (fields_d * fields_per_pass)[:fields_per_pass],
+                         (masks_d[:fields_per_pass] if len(masks_d) >= fields_per_pass else (masks_d * fields_per_pass)[:fields_per_pass]))
+            settled = gridder.settle_records(tries=args.settle_tries)        # part of the one-off geometry build: untimed
+            if settled is not None:
+                torch.cuda.synchronize()
+                settled["seconds"] = round(time.perf_counter() - t0 - t_built, 3)
         ref_format_bytes = gridder.algorithmic_bytes()          # 8 bytes per pair
         if gridder.compact is not None:
             algo_bytes = gridder.compact_bytes()                # what this kernel has to move: ~5.7 bytes per pair
@@ -570,6 +584,8 @@ def run_rank(args):
         batch_geometry = search
     torch.cuda.synchronize()
     t_geom = time.perf_counter() - t0
+    if args.mode == "csr":
+        t_geom = t_built                             # extras.geometry_build_s: the build; the settling reports its own seconds
     log(f"rank {rank}: geometry ({args.mode}) ready in {t_geom:.1f}s"
         + (f": {n_pairs:,} pairs ({n_pairs / n_vox:.1f}/voxel), {algo_bytes / 1e9:.2f} GB algorithmic per launch" if n_pairs else ""))
 
@@ -788,6 +804,7 @@ def run_rank(args):
                        "ranks_seen_by_process_group": dist.get_world_size() if world > 1 else 1,
                        "checked": checked,
                        "products": (args.products if c5 else None),
+                       "records_settled": (settled if args.mode == "csr" else None),
                        "record_order": (args.rec_order if args.mode == "csr" and gridder.compact is not None
                                  and gridder.packed_stream else None),
                 "step": "pack_fields + " + (("csr_compact_apply" if compact_on else "csr_apply") if args.mode == "csr"

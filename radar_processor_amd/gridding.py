@@ -271,6 +271,50 @@ class CsrGridder:
         ip = 8 if csr.is_i64 else 4
         return 8 * csr.n_pairs + ip * (self.n_vox + 1) + self.n_fields * (5 * self.n_gates + 4 * self.n_vox)
 
+    def settle_records(self, tries: int = 3, probe_launches: int = 3, out=None):
+        """Placement settling of the packed record array -- part of the one-off geometry build, like the reference's
+        precompute (``radar_grid/compute.py:106-284`` runs once per scan strategy, ``apply_geometry`` thousands of times).
+
+        On this part the 1.4 % of its traffic the gridding kernel WRITES costs 5-15 % of the launch depending on where the
+        driver happened to place the 44 GB it READS (EXPERIMENTS.md: thirty + twenty processes in two clusters, the placement
+        decided per allocation, nothing on the kernel's side moves it).  So: copy the records into ``tries - 1`` further
+        allocations, time ``probe_launches`` launches of this gridder's own kernel through each (the fields are whatever
+        ``packed`` holds; values do not matter to the timing), keep the fastest placement and free the others.  Needs
+        ``tries`` x the record bytes of free HBM for a moment (skipped otherwise); nothing about the results changes -- the
+        same records, the same kernel, the same bits.  Returns ``{"tries", "probe_ms", "kept"}`` or ``None`` when it did
+        not run."""
+        torch = _native.torch_mod()
+        c = self.compact
+        if not self.has_columns_kernel or tries <= 1 or c.rec is None or c.rec.numel() == 0:
+            return None
+        nbytes = int(c.rec.numel()) * c.rec.element_size()
+        free_b, _ = torch.cuda.mem_get_info(self.dev)
+        if free_b < (tries - 1) * nbytes + 4 * self.n_fields * self.n_vox + (8 << 30):
+            return None
+        with torch.cuda.device(self.dev):
+            if out is None:
+                out = torch.empty((self.n_fields, self.n_vox), dtype=torch.float32, device=self.dev)
+            candidates = [c.rec] + [torch.empty_like(c.rec).copy_(c.rec) for _ in range(tries - 1)]      # all alive at once:
+            probe_ms = []                                                                                # distinct placements
+            for cand in candidates:
+                c.rec = cand
+                self.apply(out)                                         # warm-up through this placement
+                times = []
+                for _ in range(probe_launches):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    self.apply(out)
+                    e1.record()
+                    e1.synchronize()
+                    times.append(e0.elapsed_time(e1))
+                probe_ms.append(round(float(np.median(times)), 4))
+            kept = int(np.argmin(probe_ms))
+            c.rec = candidates[kept]
+            del candidates, cand
+            torch.cuda.empty_cache()                                    # hand the losers' memory back to the driver
+        logger.info(f"Record placement settled: probe ms {probe_ms}, kept allocation {kept}")
+        return {"tries": tries, "probe_ms": probe_ms, "kept": kept}
+
     def compact_bytes(self) -> Optional[int]:
         """Bytes one launch of the compact kernel must move: 16-bit position + weight per pair, the dictionaries and
         their offsets, the row pointers, every field once, every grid once (``None`` without a compact copy)."""

@@ -793,3 +793,26 @@ def test_metric_column_mode_grid_and_products_only(metric):
     for iy in (3, 1234):
         rows = grid[:, iy, :].cpu().numpy()[:, None, :]
         np.testing.assert_array_equal(rec["cappi"][4000.0][iy].cpu().numpy(), oracle.cappi(rows, cfg["grid_limits"][0], 4000.0)[0])
+
+
+def test_c2_settling_the_record_placement_changes_nothing_but_where_the_records_live(c2):
+    """CsrGridder.settle_records: the records copied into further allocations, each probed with the gridder's own kernel, the
+    fastest kept, the others freed -- the same records, hence the same grid bit for bit; the report lists one probe per try."""
+    from radar_processor_amd.gridding import CsrGridder
+    rg, torch, geom, dev = c2["rg"], c2["torch"], c2["geom"], c2["dev"]
+    f, m = c2["fields"]["DBZH"], c2["masks"]["DBZH"]
+    g = CsrGridder(geom, f.numel(), 1, device=dev, compact=True)
+    assert g.has_columns_kernel
+    g.pack([f], [m])
+    before = torch.empty((1, g.n_vox), dtype=torch.float32, device=dev)
+    g.apply(before)
+    rec0 = g.compact.rec
+    snapshot = rec0.clone()
+    report = g.settle_records(tries=3)
+    assert report is not None and report["tries"] == 3 and len(report["probe_ms"]) == 3 and 0 <= report["kept"] < 3
+    assert all(0.3 < t < 10 for t in report["probe_ms"])
+    assert torch.equal(g.compact.rec, snapshot) and (report["kept"] == 0) == (g.compact.rec.data_ptr() == rec0.data_ptr())
+    after = torch.full_like(before, -7.0)
+    g.apply(after)
+    assert torch.equal(after.view(torch.int32), before.view(torch.int32))
+    assert g.settle_records(tries=1) is None
