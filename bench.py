@@ -72,6 +72,9 @@ def parse_args(argv=None):
                     help="csr mode, packed records: placements of the record array tried during the (untimed) geometry build -- the "
                          "fastest under a 3-launch probe of the gridding kernel is kept (CsrGridder.settle_records); 1 = off. "
                          "Reported in config.records_settled")
+    ap.add_argument("--c5-per-pass", type=int, default=0, choices=(0, 4, 8),
+                    help="C5 / extras.c5: field-volumes one pass over the geometry fuses; 0 = what batch.VolumeBatch chooses for "
+                         "the geometry (8 through the row-wise kernel where its LDS window admits eight fields, else 4)")
     ap.add_argument("--no-c5-extra", action="store_true",
                     help="skip the extras.c5 side measurement (8 seeded volumes per GPU through batch.VolumeBatch after the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -380,6 +383,8 @@ def c5_side_measurement(args, rg, batch, synthetic, torch, dist, dev, geom_or_se
             vols[b] = {"DBZH": (torch.from_numpy(np.ascontiguousarray(np.ma.getdata(v.fields["DBZH"]))).to(dev),
                                 torch.from_numpy(np.ma.getmaskarray(v.fields["DBZH"]).astype(np.uint8)).to(dev))}
         vb = batch.VolumeBatch(geom_or_search, ("DBZH",), device=dev)
+        if args.c5_per_pass and args.mode == "csr":
+            vb._cap = args.c5_per_pass
     except Exception as exc:
         err = repr(exc)
 
@@ -421,7 +426,8 @@ def c5_side_measurement(args, rg, batch, synthetic, torch, dist, dev, geom_or_se
             dt = float(t.item())
         pass_ms = [a.elapsed_time(b) for a, b in events] if err is None else []
         out[name] = {"ms_per_step": round(dt * 1e3, 3), "pass_ms_median": round(float(np.median(pass_ms)), 3) if pass_ms else None,
-                     "passes_per_step": len(pass_ms) / steps}
+                     "passes_per_step": len(pass_ms) / steps,
+                     "volumes_per_pass": (vb.volumes_per_pass if vb is not None and err is None else None)}
     bad = 0.0 if err is None else 1.0
     if world > 1:
         t = torch.tensor([bad], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
@@ -542,10 +548,13 @@ def run_rank(args):
         with tempfile.TemporaryDirectory() as tmp:
             # passes run through the compact copy of the CSR; 'auto' keeps the reference's index array next to it when
             # both fit and builds the copy alone otherwise (config 4: 33 G pairs)
-            fields_per_pass = min(4 if c5 else 8, n_ff)     # C5: VolumeBatch fuses up to 4 field-volumes into one CSR pass
             want_compact = not args.no_compact
             geom = rg.compute_grid_geometry(vol.gate_x, vol.gate_y, vol.gate_z, shape, limits, tmp,
                                             layout=args.layout if want_compact else "csr")
+            # C5: VolumeBatch fuses 8 or 4 field-volumes into one pass (gridding.volumes_per_pass_cap: per geometry)
+            from radar_processor_amd.gridding import volumes_per_pass_cap
+            c5_cap = args.c5_per_pass or volumes_per_pass_cap(geom, dev)
+            fields_per_pass = min(c5_cap if c5 else 8, n_ff)
         if want_compact and geom.device_csr(dev).gate_indices is not None:
             free_b, _ = torch.cuda.mem_get_info(dev)              # room for the copy (2.3 bytes per pair + scratch)?
             want_compact = free_b > 3.2 * geom.n_pairs() + (8 << 30)
@@ -594,6 +603,8 @@ def run_rank(args):
 
     if c5:
         vb = batch.VolumeBatch(batch_geometry, field_names, device=dev)
+        if args.c5_per_pass and args.mode == "csr":
+            vb._cap = args.c5_per_pass
         from radar_processor_amd.gridding import PlaneProducts
 
         def reducer(g):

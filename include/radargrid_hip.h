@@ -36,8 +36,9 @@ extern "C" {
  * binding (radar_processor_amd/_native.py: ABI_VERSION) refuses a library whose rg_version() differs, so a stale git-ignored
  * .so is reported as such instead of being called with shifted arguments.  History: 100 rounds 1-2; 101 rec_order / plane0 of
  * rg_csr_compact_pack and rg_csr_compact_apply_packed_f32 (round 3); 102 rg_csr_compact_apply_columns_f32, diagnostic tile
- * codes refused by the product build (round 4). */
-#define RG_VERSION 102
+ * codes refused by the product build (round 4); 103 the row-wise kernel of rg_csr_compact_apply_packed_f32 takes 1-8 fields
+ * (no signature changed: a 102 library answers RG_EUNSUPPORTED for 5-8). */
+#define RG_VERSION 103
 #define RG_MAX_FIELDS 8
 
 typedef void* rg_stream_t; /* hipStream_t */
@@ -358,14 +359,18 @@ int rg_csr_compact_apply_f32(const void* indptr, int32_t indptr_is_i64, const ui
  * rec_ptr is built by the caller.  rg_csr_compact_pack fills `records` from local_idx + weights (error_flag: 1 = rec_ptr
  * inconsistent with indptr, 2 = a weight outside the code, 4 = a segment with 2^27 records or more); for a slab of whole
  * planes of a larger grid pass the slab's indptr / n_rows, rec_ptr + the slab's first slot and plane0 = its first plane.
- * rg_csr_compact_apply_packed_f32 grids 1-4 fused fields through the records (interpolate.py:69-104, the same masked
- * weighted mean as rg_csr_apply_f32: float32 products and sums, float64 only in the final division):
+ * rg_csr_compact_apply_packed_f32 grids 1-8 fused fields (row-wise kernel; the tile kernel over the records: 1-4) through
+ * the records (interpolate.py:69-104 / :137-140, the same masked weighted mean as rg_csr_apply_f32: float32 products and sums,
+ * float64 only in the final division):
  *   tile = 0    the ROW-WISE kernel: the lanes of a row read the row's records straight from memory and sum them in
  *               registers (no LDS tile), L = 2^k lanes per row chosen per segment from its mean row length.  The order
  *               of the float32 adds is fixed by the geometry and the field count alone (reproducible run to run, on any
  *               window_cap), but it is not the order of rg_csr_apply_f32: the two agree to float32 rounding (the bar of
  *               the parity tests: 1e-5 relative + 1e-5 * max|field|), not bit for bit.  This is the fast path:
- *               1.0-1.5 ms for 1-4 fields on BASELINE config 2 where the tile kernels need 1.1-3.3 ms.
+ *               1.0-1.5 ms for 1-4 fields on BASELINE config 2 where the tile kernels need 1.1-3.3 ms.  Five to eight
+ *               fields (stride 8; eight volumes of one geometry in ONE pass over the records: 15.5 ms on the bench grid
+ *               against 2 x 10.5 for two passes of four) keep 40 bytes of LDS per window entry: worth it where the
+ *               geometry's window is <= 768 entries (the Python layer decides: gridding.fields_per_pass).
  *   tile = 384  the TILE kernel of rg_csr_compact_apply_f32 over the same records: the results of rg_csr_apply_f32 for the
  *               same fields, bit for bit (576 / 768: single-field tuning variants of it).
  *   tile = 2000 + h   row-wise with a diagnostic lane split: h = 1, 2, 4 .. 64 lanes per row, or h = 71 .. 99 = 70 + t to

@@ -184,13 +184,15 @@ def csr_apply_f64(indptr, gate_indices, weights, field_values, field_mask, grid_
     out[ok] = (num[ok] / den[ok]).astype(np.float32)
     return out.reshape(grid_shape)
 
-ROWWISE_TARGET = {1: 4, 2: 4, 3: 6, 4: 8}   # records per lane and row the row-wise kernel aims for, by field count
-ROWWISE_KPRE = {1: 3, 2: 3, 3: 3, 4: 3}     # records per lane and step (batch slots), by field count
+ROWWISE_TARGET = {1: 4, 2: 4, 3: 6, 4: 8, 5: 8, 6: 8, 7: 8, 8: 12}   # records per lane and row the row-wise kernel aims for
+ROWWISE_KPRE = {n: 3 for n in range(1, 9)}  # records per lane and step (batch slots), by field count
 ROWWISE_CHAINS = 2                          # running sums per lane and value: batch slot k adds into chain k mod 2
+ROWWISE_WEIGHT_CHAINS = {1: 2, 2: 2, 3: 2, 4: 2, 5: 1, 6: 1, 7: 1, 8: 1}   # ... of the weight sums (5-8 fields: one chain)
 
 
 def csr_apply_rowwise_order(indptr, gate_indices, weights, fields, masks, grid_shape, fill_value=np.nan,
-                            lanes_hint: int = 0, kpre: int = 0, chains: int = ROWWISE_CHAINS) -> np.ndarray:
+                            lanes_hint: int = 0, kpre: int = 0, chains: int = ROWWISE_CHAINS,
+                            weight_chains: int = 0) -> np.ndarray:
     """The masked weighted mean of :func:`csr_apply` (interpolate.py:69-104) with the float32 additions performed in
     exactly the order the row-wise kernel of ``rg_csr_compact_apply_packed_f32`` documents
     (radar_processor_amd/csrc/rg_csr_compact.hip), so that the kernel can be checked BIT FOR BIT on small cases:
@@ -202,7 +204,9 @@ def csr_apply_rowwise_order(indptr, gate_indices, weights, fields, masks, grid_s
     * lane j of a row owns the row's records q0 + j, q0 + j + L, ... (q0 = first pair // 3); its t-th record sits in
       batch slot t mod K, K = ROWWISE_KPRE[fields] (``kpre``: another K), and belongs to chain (t mod K) mod C, C =
       ``chains`` = 2; per chain one running float32 (sum w*v, sum w) per field over the chain's pairs in ascending order, a
-      masked gate adding +0 to both; the lane's chains are then added in ascending order;
+      masked gate adding +0 to both; the lane's chains are then added in ascending order; passes of 5-8 fields keep ONE
+      chain for the weight sums (``weight_chains``, default ROWWISE_WEIGHT_CHAINS[fields]): all of the lane's weights in
+      ascending pair order;
     * the L lane sums are folded by an xor butterfly (x[i] += x[i ^ 1], then ^ 2, ^ 4, ...);
     * value = float32(float64(sum w*v) / float64(sum w)) where sum w > 0, else ``fill_value``.
 
@@ -215,6 +219,7 @@ def csr_apply_rowwise_order(indptr, gate_indices, weights, fields, masks, grid_s
     nf = len(fields)
     kpre = int(kpre) if kpre else ROWWISE_KPRE[nf]
     chains = max(1, min(int(chains), kpre))
+    wchains = max(1, min(int(weight_chains) if weight_chains else ROWWISE_WEIGHT_CHAINS[nf], chains))
     vals = [np.asarray(f, dtype=np.float32) for f in fields]
     excl = [np.zeros(vals[0].shape, dtype=bool) if m is None else np.asarray(m, dtype=bool) for m in masks]
     out = np.full((nf, nz * ny * nx), fill_value, dtype=np.float32)
@@ -246,13 +251,16 @@ def csr_apply_rowwise_order(indptr, gate_indices, weights, fields, masks, grid_s
                 o = np.arange(rs, pe - seg_b)                     # pair offsets in the segment
                 q = o // 3 - rs // 3                              # record number within the row
                 lane, trip = q % lanes, q // lanes
-                chain = (trip % kpre) % chains
-                # position of the pair inside its chain: the chain's records in ascending order, three pairs each
-                per_step = [len([k for k in range(kpre) if k % chains == c]) for c in range(chains)]      # slots per chain
-                before = [[len([k for k in range(s_) if k % chains == c]) for s_ in range(kpre)] for c in range(chains)]
-                rec_in_chain = (trip // kpre) * np.asarray(per_step)[chain] + np.asarray(before)[chain, trip % kpre]
-                col = rec_in_chain * 3 + o % 3
-                width = int(col.max()) + 1
+                def place(n_chains):
+                    """(chain, column) of every pair: its chain's records in ascending order, three pairs each."""
+                    chain = (trip % kpre) % n_chains
+                    per_step = [len([k for k in range(kpre) if k % n_chains == c]) for c in range(n_chains)]   # slots per chain
+                    before = [[len([k for k in range(s_) if k % n_chains == c]) for s_ in range(kpre)] for c in range(n_chains)]
+                    rec_in_chain = (trip // kpre) * np.asarray(per_step)[chain] + np.asarray(before)[chain, trip % kpre]
+                    return chain, rec_in_chain * 3 + o % 3
+                chain, col = place(chains)
+                wchain, wcol = (chain, col) if wchains == chains else place(wchains)
+                width = int(max(col.max(), wcol.max())) + 1
                 g = gate_indices[ps:pe]
                 w = w_all[ps:pe]
                 for f in range(nf):
@@ -260,15 +268,17 @@ def csr_apply_rowwise_order(indptr, gate_indices, weights, fields, masks, grid_s
                     prod = np.where(good, w * vals[f][g], zero).astype(np.float32)   # float32 product, then the add
                     wgt = np.where(good, w, zero).astype(np.float32)
                     mp = np.zeros((chains, lanes, width), dtype=np.float32)
-                    mw = np.zeros((chains, lanes, width), dtype=np.float32)
+                    mw = np.zeros((wchains, lanes, width), dtype=np.float32)
                     mp[chain, lane, col] = prod
-                    mw[chain, lane, col] = wgt
+                    mw[wchain, lane, wcol] = wgt
                     with np.errstate(invalid="ignore", over="ignore"):
                         chain_p = np.add.accumulate(mp, axis=2, dtype=np.float32)[:, :, -1]   # strictly sequential per chain
                         chain_w = np.add.accumulate(mw, axis=2, dtype=np.float32)[:, :, -1]
                         sp, sw = chain_p[0], chain_w[0]
                         for c in range(1, chains):                                            # chains in ascending order
-                            sp, sw = (sp + chain_p[c]).astype(np.float32), (sw + chain_w[c]).astype(np.float32)
+                            sp = (sp + chain_p[c]).astype(np.float32)
+                        for c in range(1, wchains):
+                            sw = (sw + chain_w[c]).astype(np.float32)
                         m = 1
                         while m < lanes:
                             partner = np.arange(lanes) ^ m

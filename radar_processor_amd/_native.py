@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # experiment build (tools/build_experiments.py) assign ``_native.LIB_PATH`` themselves before the first load; the ABI
 # check below applies to them as well.
 LIB_PATH = os.path.join(HERE, "csrc", "libradargrid_hip.so")
-ABI_VERSION = 102          # include/radargrid_hip.h: RG_VERSION -- load_library refuses a library built from another header
+ABI_VERSION = 103          # include/radargrid_hip.h: RG_VERSION -- load_library refuses a library built from another header
 
 RG_MAX_FIELDS = 8
 RG_EXCLUDED_BITS = 0x7FD1CE5D

@@ -127,12 +127,19 @@ class VolumeBatch:
         self.dev = geometry.dev if self.fused else _native.canonical_device(device)
         if not 1 <= len(self.field_names) <= _native.RG_MAX_FIELDS:
             raise ValueError("1..8 fields per volume")
-        # measured on the bench grid (ms per fused pass): row-wise kernel over the packed records 7.9 / 8.7 / 10.1 / 11.4
-        # for 1-4 field-volumes (2.9 ms each at four; it takes at most four), rg_csr_apply_f32 13.1 / 14.9 / 18.8 / 20.7
-        # and 55.1 for eight -- four per pass either way; the CSR-free gridder keeps gaining up to 8 because it shares
-        # the whole neighbour search
-        cap = _native.RG_MAX_FIELDS if self.fused else min(4, _native.RG_MAX_FIELDS)
-        self.volumes_per_pass = max(1, cap // len(self.field_names))
+        # measured on the bench grid (ms per fused pass): row-wise kernel over the packed records 7.9 / 8.7 / 10.1 / 10.5 / 15.5
+        # for 1 / 2 / 3 / 4 / 8 field-volumes (1.9 ms each at eight, where the geometry's LDS window admits eight: decided per
+        # geometry by gridding.fields_per_pass, on first use), rg_csr_apply_f32 13.1 / 14.9 / 18.8 / 20.7 and 55.1 for eight;
+        # the CSR-free gridder keeps gaining up to 8 because it shares the whole neighbour search
+        self._cap = _native.RG_MAX_FIELDS if self.fused else None
+
+    @property
+    def volumes_per_pass(self) -> int:
+        """Volumes one pass fuses (decided on first use: the CSR path asks the geometry's device copy)."""
+        if self._cap is None:
+            from .gridding import volumes_per_pass_cap
+            self._cap = volumes_per_pass_cap(self.geometry, self.dev)
+        return max(1, self._cap // len(self.field_names))
 
     def _to_dev(self, a, dtype):
         import torch

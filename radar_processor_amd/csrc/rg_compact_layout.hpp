@@ -15,6 +15,9 @@ using rg_u32x4 = unsigned __attribute__((ext_vector_type(4)));
 __device__ rg_u32x4 rg_buffer_load_v4u32(__amdgpu_buffer_rsrc_t, int voffset, int soffset, int aux)
     __asm("llvm.amdgcn.raw.ptr.buffer.load.v4i32");
 
+__device__ unsigned rg_buffer_load_u32(__amdgpu_buffer_rsrc_t, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.raw.ptr.buffer.load.i32");
+
 // v_mul_legacy_f32 by intrinsic name (this clang has no __builtin_amdgcn_fmul_legacy): 0 * x = +0 for EVERY x, NaN and
 // infinity included; any other product is the IEEE one.
 __device__ float rg_fmul_legacy(float, float) __asm("llvm.amdgcn.fmul.legacy");
@@ -158,6 +161,43 @@ template <> struct RowwiseConfig<2> { static constexpr int kpre = 3, target = 4;
 #endif
 template <> struct RowwiseConfig<3> { static constexpr int kpre = RG_ROWWISE_KPRE3, target = RG_ROWWISE_TARGET3; static constexpr bool narrow = RG_ROWWISE_NARROW3, regs = RG_ROWWISE_REGS3; };
 template <> struct RowwiseConfig<4> { static constexpr int kpre = 3, target = 8; static constexpr bool narrow = false, regs = true; };
+// Five to eight fields (one pass over the records for up to eight volumes of the same geometry: batch.VolumeBatch)
+template <> struct RowwiseConfig<5> { static constexpr int kpre = 3, target = 8; static constexpr bool narrow = false, regs = true; };
+template <> struct RowwiseConfig<6> { static constexpr int kpre = 3, target = 8; static constexpr bool narrow = false, regs = true; };
+template <> struct RowwiseConfig<7> { static constexpr int kpre = 3, target = 8; static constexpr bool narrow = false, regs = true; };
+#if !defined(RG_EXPERIMENTS) || !defined(RG_ROWWISE_KPRE8)
+#undef RG_ROWWISE_KPRE8
+#define RG_ROWWISE_KPRE8 3
+#endif
+#if !defined(RG_EXPERIMENTS) || !defined(RG_ROWWISE_TARGET8)
+#undef RG_ROWWISE_TARGET8
+#define RG_ROWWISE_TARGET8 12
+#endif
+#if !defined(RG_EXPERIMENTS) || !defined(RG_ROWWISE_REGS8)
+#undef RG_ROWWISE_REGS8
+#define RG_ROWWISE_REGS8 true
+#endif
+template <> struct RowwiseConfig<8> { static constexpr int kpre = RG_ROWWISE_KPRE8, target = RG_ROWWISE_TARGET8; static constexpr bool narrow = false, regs = RG_ROWWISE_REGS8; };
+
+// Byte-mask window entries: the window holds v' = the value, or +0 where the gate is excluded, and one BYTE per field that is
+// 1 / 0 = usable / excluded.  A pair then costs, per field, half a packed multiply and half a packed add (sum w*v': w * +0 = +0,
+// what select + v_mul_legacy_f32 gave), a byte -> float conversion and half a packed fma (sum w*g: the product is exact, so the
+// same float32 as adding w or +0) instead of compare + select + v_mul_legacy_f32 + two half packed adds -- the same bits from
+// fewer instructions.  Three fields: the mask word is the entry's fourth slot (16-byte entries); four fields: a second array of
+// words behind the 16-byte value entries; five to eight fields: 32-byte value entries and two mask words per entry behind them.
+// Five fields and more always use it; RG_ROWWISE_BYTEMASK = the smallest field count of 3 / 4 that does (5 = neither: measured
+// equal in time on the bench grid and config 2, EXPERIMENTS.md R4.5d, so three and four fields keep the 12- / 16-byte entries).
+#if !defined(RG_EXPERIMENTS) || !defined(RG_ROWWISE_BYTEMASK)
+#undef RG_ROWWISE_BYTEMASK
+#define RG_ROWWISE_BYTEMASK 5
+#endif
+template <int NF> constexpr bool rowwise_bytemask() { return NF >= 5 || (NF >= 3 && NF >= RG_ROWWISE_BYTEMASK); }
+// 4-byte words of LDS per window entry of the row-wise kernel: values, then masks
+template <int NF> constexpr int rowwise_value_words() {
+  return rowwise_bytemask<NF>() ? (NF <= 4 ? 4 : 8) : RowwiseConfig<NF>::narrow ? 3 : NF <= 2 ? 2 : 4;
+}
+template <int NF> constexpr int rowwise_mask_words() { return !rowwise_bytemask<NF>() || NF == 3 ? 0 : NF == 4 ? 1 : 2; }
+template <int NF> constexpr int rowwise_entry_words() { return rowwise_value_words<NF>() + rowwise_mask_words<NF>(); }
 
 
 // ---- column mode of the row-wise kernel (rg_csr_compact_apply_columns_f32) --------------------------------------------------

@@ -533,7 +533,11 @@ constexpr int kRowwiseChunksPerBlock = 1;   // consecutive chunks one workgroup 
 #undef RG_ROWWISE_WAVES3
 #define RG_ROWWISE_WAVES3 1
 #endif
-#define RG_ROWWISE_BOUNDS __launch_bounds__(64 * kH, (NF == 1 ? RG_ROWWISE_WAVES1 : NF == 3 ? RG_ROWWISE_WAVES3 : 1))
+#if !defined(RG_EXPERIMENTS) || !defined(RG_ROWWISE_WAVES8)
+#undef RG_ROWWISE_WAVES8
+#define RG_ROWWISE_WAVES8 1
+#endif
+#define RG_ROWWISE_BOUNDS __launch_bounds__(64 * kH, (NF == 1 ? RG_ROWWISE_WAVES1 : NF == 3 ? RG_ROWWISE_WAVES3 : NF >= 5 ? RG_ROWWISE_WAVES8 : 1))
 // COLS (rg_csr_compact_apply_columns_f32, csrc/rg_csr_columns.hip): the chunks a workgroup takes one after the other are
 // not consecutive blocks of the dispatch order but the LEVELS of one column of chunks -- the same (line group, segment)
 // patch from plane z0 to z1 - 1 of its level piece -- so that lane == row sees the voxels of its (y, x) column in ascending
@@ -549,15 +553,38 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
     const float* __restrict__ packed, unsigned last_gate, float fill, int window_cap, long n_vox, float* __restrict__ out,
     const rg_u32x4* __restrict__ rec, const int64_t* __restrict__ rec_ptr, unsigned w_base, int lanes_hint,
     int rec_order, unsigned n_chunks, int chunks_per_block, const RowwiseColumns cols) {
-  static_assert(NF >= 1 && NF <= 4 && (STRIDE == 1 || STRIDE == 2 || STRIDE == 4), "passes of 1-4 fields");
+  static_assert(NF >= 1 && NF <= 8 && STRIDE == stride_for(NF), "passes of 1-8 fields");
   using Cfg = RowwiseConfig<NF>;
   constexpr int KPRE = Cfg::kpre;
-  constexpr bool kNarrow = Cfg::narrow, kRegs = REGS < 0 ? Cfg::regs : REGS != 0;
+  // Record prefetch (experiment builds only; measured SLOWER, EXPERIMENTS.md R4.9): touch loads -- one dword per 64 bytes, never
+  // read -- of the segment's first kPrefetchHead bytes before the window fill and, when round rho begins, of the records of round
+  // rho + kPrefetch - 1, so that the real loads would hit in L2.
+#if defined(RG_EXPERIMENTS) && defined(RG_ROWWISE_PREFETCH)
+  constexpr int kPrefetch = NF >= RG_ROWWISE_PREFETCH_MIN_NF ? RG_ROWWISE_PREFETCH : 0;
+  constexpr int kPrefetchHead = RG_ROWWISE_PREFETCH_HEAD;
+#else
+  constexpr int kPrefetch = 0;
+  constexpr int kPrefetchHead = 0;
+#endif
+  constexpr bool kByteMask = rowwise_bytemask<NF>();       // window entries = (v' ..., byte mask): rg_compact_layout.hpp
+  constexpr bool kNarrow = Cfg::narrow && !kByteMask, kRegs = REGS < 0 ? Cfg::regs : REGS != 0;
   // one field: the window holds (v', m) = (value, 1) of a gate, (0, 0) where it is excluded, so that a pair contributes
   // w * (v', m) -- the same float32 values as selecting on the EXCLUDED sentinel (w * 0 = +0, w * 1 = w) in two packed
   // instructions instead of a compare, two selects, a product and two adds
   constexpr bool kPremask = NF == 1;
-  extern __shared__ __attribute__((aligned(16))) float window[];   // window_cap + 1 entries of STRIDE (kNarrow: 3) floats
+  extern __shared__ __attribute__((aligned(16))) float window[];   // window_cap + 1 entries of rowwise_entry_words<NF>() words
+  // byte masks of four fields and more: the mask words of the window_cap + 1 entries lie behind their value entries
+  constexpr int kVW = rowwise_value_words<NF>(), kMW = rowwise_mask_words<NF>();
+  // the mask byte of a usable field: 1 (read back with v_cvt_f32_ubyteN, one per field) or the fp8 (OCP e4m3) code of 1.0 (read
+  // back two fields at a time with v_cvt_pk_f32_fp8)
+#if defined(RG_EXPERIMENTS) && defined(RG_ROWWISE_MASK_UBYTE)
+  constexpr bool kMaskFp8 = false;
+#else
+  constexpr bool kMaskFp8 = true;
+#endif
+  constexpr unsigned kMaskOne = kMaskFp8 ? 0x38u : 1u;
+  (void)kMW;
+  unsigned* const maskw = reinterpret_cast<unsigned*>(window + (size_t)(window_cap + 1) * kVW);
   __shared__ f32x2 rowacc_all[kRegs ? 1 : kH][kRegs ? 2 : 64 * NF];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -661,6 +688,15 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
     trips_row = o > trips_row ? o : trips_row;
   }
 
+  // ---- record prefetch (see run(): kPrefetch) -- the segment's first records are touched before the window fill -------
+  unsigned pf_d0 = 0, pf_d1 = 0;
+  if constexpr (kPrefetch > 0) {
+    if (span > 0) {
+      pf_d0 = rg_buffer_load_u32(rr, lane * 64, 0, 0);              // out-of-range pieces return 0 without a memory access
+      if constexpr (kPrefetchHead > 4096) pf_d1 = rg_buffer_load_u32(rr, 4096 + lane * 64, 0, 0);
+    }
+  }
+
   // ---- the chunk's field window + the sentinel entry ----------------------------------------------------------
   // kFillBatch entries per thread at a time: their dictionary reads are issued back to back, then their field gathers, then
   // the LDS stores -- two memory latencies per batch.  (Round 2 walked the entries one by one: dictionary read, wait, gather,
@@ -704,7 +740,26 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
 #pragma unroll
           for (int s = 0; s < STRIDE; ++s) v[u][s] = __builtin_bit_cast(float, RG_EXCLUDED_BITS);
         }
-        if constexpr (kNarrow) {
+        if constexpr (kByteMask) {
+          unsigned m[2] = {0u, 0u};
+          float vv[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+          for (int f = 0; f < NF; ++f) {
+            const bool good = rg::f32_bits(v[u][f]) != RG_EXCLUDED_BITS;
+            vv[f] = good ? v[u][f] : 0.0f;
+            m[f >> 2] |= good ? (kMaskOne << (8 * (f & 3))) : 0u;
+          }
+          if constexpr (NF == 3) {
+            reinterpret_cast<f32x4*>(window)[i] = (f32x4){vv[0], vv[1], vv[2], __builtin_bit_cast(float, m[0])};
+          } else if constexpr (NF == 4) {
+            reinterpret_cast<f32x4*>(window)[i] = (f32x4){vv[0], vv[1], vv[2], vv[3]};
+            maskw[i] = m[0];
+          } else {
+            reinterpret_cast<f32x4*>(window)[2 * i] = (f32x4){vv[0], vv[1], vv[2], vv[3]};
+            reinterpret_cast<f32x4*>(window)[2 * i + 1] = (f32x4){vv[4], vv[5], vv[6], vv[7]};
+            reinterpret_cast<uint2*>(maskw)[i] = make_uint2(m[0], m[1]);
+          }
+        } else if constexpr (kNarrow) {
           window[i * 3] = v[u][0]; window[i * 3 + 1] = v[u][1]; window[i * 3 + 2] = v[u][2];
         } else if constexpr (kPremask) {
           const bool good = rg::f32_bits(v[u][0]) != RG_EXCLUDED_BITS;
@@ -786,11 +841,24 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
 #else
     constexpr int KS = 2;
 #endif
-    float ap[KS][NF], aw[KS][NF];
+    // Five fields and more: the weight sums keep ONE chain.  They add positive terms only, so their rounding is a few 1e-8
+    // of the sum whatever the order; the products -- where mixed signs cancel and the order shows in the result -- keep two.
+    // (Eight fields: 165 VGPRs with two chains each, 3 wavefronts per SIMD; 4 wavefronts need <= 128.)
+#if defined(RG_EXPERIMENTS) && defined(RG_ROWWISE_WSLOTS8)
+    constexpr int KSW = NF >= 5 ? (RG_ROWWISE_WSLOTS8 < KS ? RG_ROWWISE_WSLOTS8 : KS) : KS;
+#else
+    constexpr int KSW = NF >= 5 ? 1 : KS;
+#endif
+    float ap[KS][NF], aw[KSW][NF];
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
 #pragma unroll
-      for (int f = 0; f < NF; ++f) ap[k][f] = aw[k][f] = 0.0f;
+      for (int f = 0; f < NF; ++f) ap[k][f] = 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < KSW; ++k) {
+#pragma unroll
+      for (int f = 0; f < NF; ++f) aw[k][f] = 0.0f;
     }
     auto consume = [&](const Step& r, const rg_u32x4& q4, int k) {     // k: slot of the step's batch (compile-time)
       // the record's pairs i = 0, 1, 2 belong to the lane's row iff lo <= i < lo + len (len = 0 for a lane without record)
@@ -817,12 +885,56 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
         if constexpr (kWindowed) {
           const int e = mine ? p : nd_all;          // not this row's pair: the all-EXCLUDED sentinel entry
           __builtin_assume((unsigned)e <= 65536u);  // lets e * 12 be a 24-bit multiply-add instead of a 64-bit one
-          if constexpr (kNarrow) {
+          if constexpr (kByteMask) {
+            // (v', byte mask): sum w*v' by multiply + add (w * +0 = +0 where excluded, as the select + legacy multiply gave),
+            // sum w*g by fma (exact product: the same float32 as adding w or +0)
+            float vv[8];
+            unsigned m[2] = {0u, 0u};
+            if constexpr (NF <= 4) {
+              const f32x4 x = reinterpret_cast<const f32x4*>(window)[e];
+              vv[0] = x.x; vv[1] = x.y; vv[2] = x.z; vv[3] = x.w;
+              m[0] = NF == 3 ? rg::f32_bits(x.w) : maskw[e];
+            } else {
+              const f32x4 x = reinterpret_cast<const f32x4*>(window)[2 * e], y = reinterpret_cast<const f32x4*>(window)[2 * e + 1];
+              vv[0] = x.x; vv[1] = x.y; vv[2] = x.z; vv[3] = x.w; vv[4] = y.x; vv[5] = y.y; vv[6] = y.z; vv[7] = y.w;
+              const uint2 mm = reinterpret_cast<const uint2*>(maskw)[e];
+              m[0] = mm.x; m[1] = mm.y;
+            }
+            float g[8];
+            if constexpr (kMaskFp8) {      // one conversion per field PAIR: v_cvt_pk_f32_fp8 (OCP e4m3: 0x38 = 1.0, 0x00 = +0)
+              const auto g01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)m[0], false);
+              g[0] = g01[0]; g[1] = g01[1];
+              if constexpr (NF > 2) {
+                const auto g23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)m[0], true);
+                g[2] = g23[0]; g[3] = g23[1];
+              }
+              if constexpr (NF > 4) {
+                const auto g45 = __builtin_amdgcn_cvt_pk_f32_fp8((int)m[1], false);
+                g[4] = g45[0]; g[5] = g45[1];
+              }
+              if constexpr (NF > 6) {
+                const auto g67 = __builtin_amdgcn_cvt_pk_f32_fp8((int)m[1], true);
+                g[6] = g67[0]; g[7] = g67[1];
+              }
+            } else {
+#pragma unroll
+              for (int f = 0; f < NF; ++f) g[f] = (float)((m[f >> 2] >> (8 * (f & 3))) & 0xFFu);
+            }
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+              ap[k % KS][f] += w[i] * vv[f];
+              aw[k % KSW][f] = __builtin_fmaf(w[i], g[f], aw[k % KSW][f]);
+            }
+#if defined(RG_EXPERIMENTS) && defined(RG_ROWWISE_PAIR_FENCE)
+            if constexpr (NF >= 5) __builtin_amdgcn_sched_barrier(0);
+#endif
+            continue;
+          } else if constexpr (kNarrow) {
             v[0] = window[e * 3]; v[1] = window[e * 3 + 1]; v[2] = window[e * 3 + 2];
           } else if constexpr (kPremask) {
             const f32x2 term = (f32x2){w[i], w[i]} * reinterpret_cast<const f32x2*>(window)[e];
             ap[k % KS][0] += term.x;
-            aw[k % KS][0] += term.y;
+            aw[k % KSW][0] += term.y;
             continue;
           } else if constexpr (STRIDE == 1) {
             v[0] = window[e];
@@ -849,13 +961,16 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
           // unmasked NaN / Inf data propagates exactly as before: same bits as good ? w * v : 0)
 #if defined(RG_EXPERIMENTS) && defined(RG_ROWWISE_TWO_SELECTS)   // A/B builds only: round 2's form of the same arithmetic
           ap[k % KS][f] += good ? w[i] * v[f] : 0.0f;
-          aw[k % KS][f] += good ? w[i] : 0.0f;
+          aw[k % KSW][f] += good ? w[i] : 0.0f;
 #else
           const float wf = good ? w[i] : 0.0f;
           ap[k % KS][f] += rg_fmul_legacy(wf, v[f]);
-          aw[k % KS][f] += wf;
+          aw[k % KSW][f] += wf;
 #endif
         }
+        // the per-pair path of an over-wide chunk (rare): five fields and more take its pairs one at a time -- three 32-byte
+        // gathers in flight per record would set the whole kernel's register count (167 instead of <= 128 for eight fields)
+        if constexpr (!kWindowed && NF >= 5) __builtin_amdgcn_sched_barrier(0);
       }
     };
     // sums of step r's batch; `last`: the round ends here -> fold the row's lanes and hand the sums to the row
@@ -873,8 +988,12 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
 #pragma unroll
         for (int k = 1; k < KS; ++k) {
           sp += ap[k][f];
+          ap[k][f] = 0.0f;
+        }
+#pragma unroll
+        for (int k = 1; k < KSW; ++k) {
           sw += aw[k][f];
-          ap[k][f] = aw[k][f] = 0.0f;
+          aw[k][f] = 0.0f;
         }
         sv[2 * f] = sp;
         sv[2 * f + 1] = sw;
@@ -896,23 +1015,45 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
       }
     };
 
+    // touch the records of round rho (its rows are consecutive, so its records are one byte range; the first 4 KiB of it)
+    auto prefetch_round = [&](int rho) {
+      if (rho >= rounds) return;                                          // wave-uniform
+      const int first = rho * rpr;
+      const int last = (first + rpr < nrows ? first + rpr : nrows) - 1;
+      const unsigned b = (unsigned)__builtin_amdgcn_readlane(rs_o, first), e = (unsigned)__builtin_amdgcn_readlane(re_o, last);
+      const int ob = (int)(b / 3u) * 16, oe = (int)((e + 2u) / 3u) * 16;
+      const int off = ob + lane * 64;
+      asm volatile("" : : "v"(pf_d0));                                   // the previous touch has long returned
+      pf_d0 = rg_buffer_load_u32(rr, off < oe ? off : kOutOfRange, 0, 0);
+    };
     rg_u32x4 regs_a[KPRE], regs_b[KPRE];
     Step sa = setup(0), sb;
     issue(sa, regs_a);
     for (;;) {     // two register stages, alternating: nothing in flight is ever copied
       sb = advance(sa);
       issue(sb, regs_b);
+      if constexpr (kPrefetch > 0) {
+        if (sb.rho != sa.rho) prefetch_round(sb.rho + kPrefetch - 1);    // behind the real loads in the (in-order) queue
+      }
       process(sa, regs_a, sb.rho != sa.rho);
       if (sb.rho >= rounds) break;
       sa = advance(sb);
       issue(sa, regs_a);
+      if constexpr (kPrefetch > 0) {
+        if (sa.rho != sb.rho) prefetch_round(sa.rho + kPrefetch - 1);
+      }
       process(sb, regs_b, sa.rho != sb.rho);
       if (sa.rho >= rounds) break;
     }
   };
   if (span > 0) {
+#if defined(RG_EXPERIMENTS) && defined(RG_ROWWISE_NO_FALLBACK)     // register-count probe only: over-wide chunks are skipped
+    if (windowed) run(std::true_type{});
+#else
     if (windowed) run(std::true_type{}); else run(std::false_type{});
+#endif
   }
+  if constexpr (kPrefetch > 0) asm volatile("" : : "v"(pf_d0), "v"(pf_d1));      // the touches end here
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -979,7 +1120,7 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
 // workgroups per CU next to the 8 KiB array.
 constexpr long kLdsPerCu = 160 * 1024;
 inline bool rowwise_lds_rowsums(int nf, int window_cap) {
-  return nf == 4 && ((long)(window_cap + 1) * 16 + (long)kH * 64 * 4 * 8 + 512) * 5 <= kLdsPerCu;
+  return nf == 4 && ((long)(window_cap + 1) * 4 * rowwise_entry_words<4>() + (long)kH * 64 * 4 * 8 + 512) * 5 <= kLdsPerCu;
 }
 
 template <typename IndT, int NF, int DIAG = 0>
@@ -987,7 +1128,7 @@ int launch_rowwise(int window_cap, const void* indptr, const int64_t* dict_ptr, 
                    long n_vox, const float* packed, long n_gates, float fill, float* out, hipStream_t s,
                    const PackedStream& ps, int lanes_hint, int chunks_per_block = 0) {
   constexpr int STRIDE = stride_for(NF);
-  constexpr int WS = RowwiseConfig<NF>::narrow ? 3 : NF == 1 ? 2 : STRIDE;        // floats per window entry
+  constexpr int WS = rowwise_entry_words<NF>();                                   // 4-byte words per window entry
   const bool lds_sums = DIAG == 0 && rowwise_lds_rowsums(NF, window_cap);
   const long kStatic = (RowwiseConfig<NF>::regs && !lds_sums) ? 16 : (long)kH * 64 * NF * 8;   // the row-sum array, if any
   // one entry beyond window_cap: the sentinel; a smaller window only sends more chunks down the per-pair path
@@ -1020,7 +1161,7 @@ static int launch_rowwise_columns_t(int window_cap, const void* indptr, const in
                                     hipStream_t s, const void* rec, const int64_t* rec_ptr, unsigned w_base, int rec_order,
                                     int lanes_hint, const RowwiseColumns& cols) {
   constexpr int STRIDE = stride_for(NF);
-  constexpr int WS = RowwiseConfig<NF>::narrow ? 3 : NF == 1 ? 2 : STRIDE;
+  constexpr int WS = rowwise_entry_words<NF>();
   constexpr int kRegsCols = -1;      // (four fields with the row sums in LDS: 108 instead of 111 VGPRs, the same 4 wavefronts)
   constexpr long kStatic = RowwiseConfig<NF>::regs ? 16 : (long)kH * 64 * NF * 8;
   const long room = (65536 - kStatic - 256) / (4 * WS) - 1;
@@ -1090,7 +1231,11 @@ int launch_rowwise_nf(int nf, int window_cap, const void* indptr, const int64_t*
     case 1: return RG_ROW(1);
     case 2: return RG_ROW(2);
     case 3: return RG_ROW(3);
-    default: return RG_ROW(4);
+    case 4: return RG_ROW(4);
+    case 5: return RG_ROW(5);
+    case 6: return RG_ROW(6);
+    case 7: return RG_ROW(7);
+    default: return RG_ROW(8);
   }
 #undef RG_ROW
 }
@@ -1123,9 +1268,10 @@ extern "C" int rg_csr_compact_apply_packed_f32(const void* indptr, int32_t indpt
              "768) or 2000 + lane split");
   RG_REQUIRE(rec_order == RG_REC_ORDER_SEGMENT || rec_order == RG_REC_ORDER_DISPATCH, RG_EINVAL,
              "rg_csr_compact_apply_packed_f32: rec_order=%d is neither RG_REC_ORDER_SEGMENT nor RG_REC_ORDER_DISPATCH", rec_order);
-  RG_REQUIRE(n_fields >= 1 && n_fields <= 4, RG_EUNSUPPORTED,
-             "rg_csr_compact_apply_packed_f32: n_fields=%d not in 1..4 (5-8 fields use 128-pair tiles, not a whole number "
-             "of 64-record loads)", n_fields);
+  RG_REQUIRE(n_fields >= 1 && n_fields <= (rowwise ? 8 : 4), RG_EUNSUPPORTED,
+             "rg_csr_compact_apply_packed_f32: n_fields=%d not in 1..%d (the row-wise kernel takes 1-8 fields; the tile kernel "
+             "over the records 1-4: 5-8 fields use 128-pair tiles, not a whole number of 64-record loads)", n_fields,
+             rowwise ? 8 : 4);
   RG_REQUIRE(stride == stride_for(n_fields), RG_EINVAL, "rg_csr_compact_apply_packed_f32: stride=%d, expected %d for %d fields",
              stride, stride_for(n_fields), n_fields);
   RG_REQUIRE(indptr && out && dict_ptr && rec_ptr, RG_EINVAL, "rg_csr_compact_apply_packed_f32: null indptr/dict_ptr/rec_ptr/out");

@@ -207,16 +207,18 @@ class CompactCSR:
         return (plane * nyg + y // _native.RG_COMPACT_LINES) * nsx + sx
 
     @staticmethod
-    def entry_bytes(n_fields: int) -> int:
+    def entry_bytes(n_fields: int, rowwise: bool = False) -> int:
         """Bytes of one LDS window entry of the compact kernels: the packed slots of a gate (2, 4 or 8 floats), a 3-field
         entry without its padding slot; one field: the value and a 0/1 factor (row-wise kernel; the tile kernel keeps the
-        value alone)."""
-        return 4 * (2 if n_fields <= 2 else 3 if n_fields == 3 else 4 if n_fields == 4 else 8)
+        value alone); 5-8 fields through the row-wise kernel (``rowwise``): 8 values + 8 mask bytes."""
+        if n_fields > 4:
+            return 40 if rowwise else 32
+        return 4 * (2 if n_fields <= 2 else 3 if n_fields == 3 else 4)
 
-    def window_for(self, n_fields: int, lds_budget_bytes: int = 32768) -> int:
+    def window_for(self, n_fields: int, lds_budget_bytes: int = 32768, rowwise: bool = False) -> int:
         """LDS window (entries) for a pass of ``n_fields`` fields: the geometry's 99.9 % window if its entries fit
         ``lds_budget_bytes``, else the largest that does."""
-        room = max(0, lds_budget_bytes // self.entry_bytes(n_fields)) // 64 * 64
+        room = max(0, lds_budget_bytes // self.entry_bytes(n_fields, rowwise)) // 64 * 64
         return int(min(self.window_cap, room))
 
     def fallback_fraction(self, window: int) -> float:

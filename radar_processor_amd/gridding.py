@@ -100,9 +100,6 @@ class CsrGridder:
         self.packed = torch.empty(max(self.n_gates, 1) * self.stride, dtype=torch.float32, device=self.dev)
         compact_only = self.csr.gate_indices is None
         packed_only = self.csr.weights is None           # only the packed pair stream exists (layout="packed")
-        if packed_only and self.n_fields > 4:
-            raise _native.NativeError("this geometry holds only the packed pair stream, which serves passes of 1-4 fields; "
-                                      "grid larger groups in several passes (grid_fields_device does)")
         # Which kernel (ms per pass on config 2 / the bench grid, MI355X):
         #                              1 field        2 fields       3 fields       4 fields       8 fields
         #   rg_csr_apply_f32           1.9 / 13.1     2.1 / 14.7     2.3 / 16.5     3.0 / 20.5     7.3 / 49.8
@@ -123,8 +120,9 @@ class CsrGridder:
         if self.compact is not None:
             # passes of 1-4 fields stream the packed records (positions + weights, 5.33 bytes per pair) when the geometry's
             # weights allow the lossless 26-bit code and the memory is there
-            self.packed_stream = bool((packed or packed_only) and self.n_fields <= 4
-                                      and self.compact.ensure_packed(self.csr))
+            self.packed_stream = bool((packed or packed_only) and self.compact.ensure_packed(self.csr))
+            if self.packed_stream:
+                self.window = self.compact.window_for(self.n_fields, rowwise=True)
             if (not self.packed_stream and not compact_only
                     and self.window * self.compact.entry_bytes(self.n_fields) > _COMPACT_MAX_WINDOW_BYTES):
                 self.compact, self.window = None, 0
@@ -188,7 +186,7 @@ class CsrGridder:
     @property
     def has_columns_kernel(self) -> bool:
         """The column mode of the row-wise kernel reads the packed records: 1-4 fields, codable weights."""
-        return self.compact is not None and self.packed_stream
+        return self.compact is not None and self.packed_stream and self.n_fields <= 4
 
     def _column_plan(self, z_pieces: int):
         """``(z_pieces, order tensor)`` for this geometry: enough workgroups to fill the chip (a workgroup is one column
@@ -356,17 +354,40 @@ def _use_compact(geometry: GridGeometry, dev) -> bool:
 
 
 def _fields_per_pass(geometry: GridGeometry, dev, use_compact: bool) -> int:
-    """Fields one CSR pass should fuse: 4 when the passes run through the packed records (the row-wise kernel takes 1-4
-    fields and two passes of four cost less than one of eight through any other kernel: 2 x 11.4 against 49.8 ms on the
-    bench grid), 8 (``RG_MAX_FIELDS``) otherwise."""
+    """Fields one CSR pass should fuse.  Through the packed records (the row-wise kernel, 1-8 fields): 8 where the geometry's
+    LDS window holds 40-byte entries (bench grid: one pass of eight 15.5 ms against two of four 2 x 10.5), 4 where it does not
+    (config 2's 1792-entry window: one pass of eight 3.4-3.9 ms against 2 x 1.4); 8 (``RG_MAX_FIELDS``) through the other
+    kernels."""
     csr = geometry.device_csr(dev)
+    compact = None
     if csr.weights is None:                 # packed-only geometry
-        return 4
-    if use_compact and csr.n_pairs:
         compact = geometry.device_compact(dev)
-        if compact is not None and compact.ensure_packed(csr):
-            return 4
+    elif use_compact and csr.n_pairs:
+        compact = geometry.device_compact(dev)
+        if compact is not None and not compact.ensure_packed(csr):
+            compact = None
+    if compact is not None:
+        return 8 if compact.window_for(8, rowwise=True) >= compact.window_cap else 4
     return _native.RG_MAX_FIELDS
+
+
+def fields_per_pass(geometry: GridGeometry, device=None) -> int:
+    """How many fields (or field-volumes of a batch) ``grid_fields_device`` fuses into one pass over this geometry on
+    ``device`` (builds the device copy if it does not exist yet)."""
+    dev = _native.canonical_device(device)
+    return _fields_per_pass(geometry, dev, _use_compact(geometry, dev))
+
+
+def volumes_per_pass_cap(geometry: GridGeometry, device=None) -> int:
+    """Field-volumes of a batch one pass should fuse (``batch.VolumeBatch``): what the packed records take (8 or 4, see
+    ``_fields_per_pass``); 4 through ``rg_csr_apply_f32`` (bench grid: 20.7 ms for four, 55.1 for eight)."""
+    dev = _native.canonical_device(device)
+    use_compact = _use_compact(geometry, dev)
+    csr = geometry.device_csr(dev)
+    if csr.weights is None or (use_compact and csr.n_pairs and geometry.device_compact(dev) is not None
+                               and geometry.device_compact(dev).ensure_packed(csr)):
+        return _fields_per_pass(geometry, dev, use_compact)
+    return min(4, _native.RG_MAX_FIELDS)
 
 
 def _cached_gridder(geometry: GridGeometry, n_gates: int, n_fields: int, dev, compact: bool) -> "CsrGridder":
@@ -492,6 +513,8 @@ def grid_products_device(geometry: GridGeometry, fields: Sequence, masks: Option
     with torch.cuda.device(dev):
         use_compact = _use_compact(geometry, dev)
         per_pass = _fields_per_pass(geometry, dev, use_compact)
+        if fused:                                # the products epilogue (column mode of the row-wise kernel) takes 1-4 fields
+            per_pass = min(per_pass, 4)
         for f0 in range(0, n_fields, per_pass):
             f1 = min(n_fields, f0 + per_pass)
             nf = f1 - f0

@@ -453,19 +453,21 @@ def test_compact_and_packed_kernels_fuzz(rg, seed):
     pos, w_back = compact._record_fields(csr, 0, n_vox)
     assert torch.equal(pos, compact.local_idx.to(torch.int64) & 0xFFFF)
     assert torch.equal(w_back.view(torch.int32), csr.weights.view(torch.int32))
-    fields = [torch.from_numpy(rng.normal(10, 20, n_gates).astype(np.float32)).to(dev) for _ in range(4)]
-    masks = [torch.from_numpy((rng.random(n_gates) < 0.2).astype(np.uint8)).to(dev) if k % 2 == 0 else None for k in range(4)]
+    fields = [torch.from_numpy(rng.normal(10, 20, n_gates).astype(np.float32)).to(dev) for _ in range(8)]
+    masks = [torch.from_numpy((rng.random(n_gates) < 0.2).astype(np.uint8)).to(dev) if k % 2 == 0 else None for k in range(8)]
+    fields[6][4::9] = float("nan")
+    fields[5][::23] = float("inf")
     fields[1][::7] = float("nan")                                      # unmasked NaN propagates like in NumPy
     fields[1][3::11] = float("inf")                                    # ... and so do unmasked infinities (Inf - Inf = NaN)
     fields[1][5::13] = float("-inf")
     fields[1][1::17] = 1e-40                                           # a denormal value: the product is not flushed
     fields[0][2::19] = -0.0
-    for nf in (1, 2, 3, 4):
+    for nf in (1, 2, 3, 4, 5, 6, 7, 8):      # 5-8 fields: the row-wise kernel only (the tile kernel over the records takes 1-4)
         g_s = CsrGridder(geom, n_gates, nf, device=dev)
         g_p = CsrGridder(geom, n_gates, nf, device=dev)
         g_p.compact, g_p.window, g_p.packed_stream, g_p.tile = compact, compact.window_for(nf), True, 384
         g_r = CsrGridder(geom, n_gates, nf, device=dev)
-        g_r.compact, g_r.window, g_r.packed_stream = compact, compact.window_for(nf), True
+        g_r.compact, g_r.window, g_r.packed_stream = compact, compact.window_for(nf, rowwise=True), True
         g_c = CsrGridder(geom, n_gates, nf, device=dev)
         g_c.compact, g_c.window, g_c.packed_stream = compact, compact.window_for(nf), False
         want = torch.empty((nf, n_vox), dtype=torch.float32, device=dev)
@@ -473,14 +475,19 @@ def test_compact_and_packed_kernels_fuzz(rg, seed):
             gr.pack(fields[:nf], masks[:nf])
         g_s.apply(want, fill_value=-3.0)
         for name, gr in (("packed", g_p), ("compact", g_c)):
+            if nf > 4 and name == "packed":
+                with pytest.raises(rg.NativeError, match="tile kernel"):
+                    gr.apply(torch.full_like(want, 9.0), fill_value=-3.0)
+                continue
             got = torch.full_like(want, 9.0)
             gr.apply(got, fill_value=-3.0)
             assert torch.equal(got.view(torch.int32), want.view(torch.int32)), (name, nf, shape)
         # window too small for most chunks: the per-pair path of the packed kernel
-        g_p.window = 0
         got = torch.full_like(want, 9.0)
-        g_p.apply(got, fill_value=-3.0)
-        assert torch.equal(got.view(torch.int32), want.view(torch.int32)), ("packed, no window", nf, shape)
+        if nf <= 4:
+            g_p.window = 0
+            g_p.apply(got, fill_value=-3.0)
+            assert torch.equal(got.view(torch.int32), want.view(torch.int32)), ("packed, no window", nf, shape)
         # the row-wise kernel: another order of the float32 adds
         row = torch.full_like(want, 9.0)
         g_r.apply(row, fill_value=-3.0)
@@ -493,8 +500,8 @@ def test_compact_and_packed_kernels_fuzz(rg, seed):
         # for the shipped lane split and for diagnostic ones (1 lane per row ... 64 lanes per row, other targets)
         f_np = [t.cpu().numpy() for t in fields[:nf]]
         m_np = [None if t is None else t.cpu().numpy().astype(bool) for t in masks[:nf]]
-        g_r.window = compact.window_for(nf)
-        for hint in ((0, 1, 8, 64, 71, 99) if nf in (1, 3) and seed < 4 else (0,)):
+        g_r.window = compact.window_for(nf, rowwise=True)
+        for hint in ((0, 1, 8, 64, 71, 99) if nf in (1, 3, 8) and seed < 4 else (0,)):
             g_r.tile = 2000 + hint if hint else 0
             got.fill_(9.0)
             g_r.apply(got, fill_value=-3.0)

@@ -363,6 +363,9 @@ def test_c2_passes_use_the_compact_copy_from_the_first(c2):
     scale = float(c2["fields"]["DBZH"][torch.isfinite(c2["fields"]["DBZH"])].abs().max())
     assert_same_to_rounding(two_a.view(2, -1), std, scale)
     assert_same_to_rounding(first.view(1, -1), std[:1], scale)
+    # a 1792-entry window does not hold the 40-byte entries of an eight-field pass: groups of four on this geometry
+    from radar_processor_amd import batch, gridding
+    assert gridding.volumes_per_pass_cap(geom, dev) == 4 and batch.VolumeBatch(geom, ["DBZH"], device=dev).volumes_per_pass == 4
 
 
 def test_c2_compact_only_layout(c2, tmp_path):
@@ -816,3 +819,52 @@ def test_c2_settling_the_record_placement_changes_nothing_but_where_the_records_
     g.apply(after)
     assert torch.equal(after.view(torch.int32), before.view(torch.int32))
     assert g.settle_records(tries=1) is None
+
+
+def test_metric_eight_volumes_in_one_pass(metric):
+    """Eight field-volumes -- eight seeded DBZH volumes of a batch, what batch.VolumeBatch fuses on this geometry -- in ONE
+    row-wise pass over the records (5-8 fields: byte-mask window entries, one chain for the weight sums): against two passes
+    of four on every voxel (the same products, another add order of the weights: float32 rounding) and against
+    ``oracle.csr_apply`` (interpolate.py:69-104) on whole rows; the pass size is the geometry's choice (8 here: a 768-entry
+    window holds 40-byte entries; config 2's 1792-entry window does not: 4)."""
+    from radar_processor_amd import batch, gridding, synthetic
+    from radar_processor_amd.gridding import CsrGridder
+    rg, torch, geom, dev, cfg = (metric[k] for k in ("rg", "torch", "geom", "dev", "cfg"))
+    vols = [metric["vol"]] + [synthetic.make_volume(cfg["n_elev"], cfg["n_az"], cfg["n_gates"], seed=s, fields=("DBZH",))
+                             for s in range(1, 8)]
+    host = [oracle.merge_masks(v.fields["DBZH"]) for v in vols]
+    f = [torch.from_numpy(np.ascontiguousarray(d)).to(dev) for d, _ in host]
+    m = [torch.from_numpy(k.astype(np.uint8)).to(dev) for _, k in host]
+    assert gridding.volumes_per_pass_cap(geom, dev) == 8 and batch.VolumeBatch(geom, ["DBZH"], device=dev).volumes_per_pass == 8
+    g8 = CsrGridder(geom, f[0].numel(), 8, device=dev, compact=True)
+    assert g8.packed_stream and g8.tile == 0 and g8.window == 768
+    g8.pack(f, m)
+    out8 = torch.full((8, g8.n_vox), -7.0, dtype=torch.float32, device=dev)
+    g8.apply(out8)
+    g4 = CsrGridder(geom, f[0].numel(), 4, device=dev, compact=True)
+    out4 = torch.empty((4, g8.n_vox), dtype=torch.float32, device=dev)
+    for lo in (0, 4):
+        g4.pack(f[lo:lo + 4], m[lo:lo + 4])
+        g4.apply(out4)
+        for k in range(4):
+            d, msk = host[lo + k]
+            assert_same_to_rounding(out8[lo + k], out4[k], scale=float(np.abs(d[np.isfinite(d) & ~msk]).max()))
+    del out4
+    nz, ny, nx = cfg["grid_shape"]
+    csr = geom.device_csr(dev)
+    for r in (0, 20 * ny + 1000, 33 * ny + 17, nz * ny - 1):
+        v0 = r * nx
+        ip = csr.indptr[v0:v0 + nx + 1].cpu().numpy().astype(np.int64)
+        idx = csr.gate_indices[int(ip[0]):int(ip[-1])].cpu().numpy()
+        w = csr.weights[int(ip[0]):int(ip[-1])].cpu().numpy()
+        for k in (0, 3, 4, 7):
+            d, msk = host[k]
+            want = oracle.csr_apply(ip - ip[0], idx, w, d, msk, (1, 1, nx))[0, 0]
+            assert_same_to_rounding(out8[k, v0:v0 + nx], want, scale=float(np.abs(d[np.isfinite(d) & ~msk]).max()))
+    # the batch driver takes the same pass: 8 volumes -> one launch, the same bits
+    vb = batch.VolumeBatch(geom, ["DBZH"], device=dev)
+    events = []
+    got = vb.grid_shard([{"DBZH": (f[b], m[b])} for b in range(8)], events=events)
+    assert len(events) == 1
+    for b in (0, 5, 7):
+        assert torch.equal(got[b][0].reshape(-1).view(torch.int32), out8[b].view(torch.int32))

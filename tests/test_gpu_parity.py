@@ -171,6 +171,7 @@ def test_compact_kernel_matches_reference(rg, name):
     m_t = [torch.from_numpy(m.astype(np.uint8)).to(dev) for _, m in data_mask]
     shape = tuple(meta["grid_shape"])
     groups = [[i] for i in range(len(names))] + ([list(range(len(names)))] if len(names) > 1 else [])
+    groups += [[i % len(names) for i in range(n)] for n in (5, 8)]         # 5-8 fields: eight volumes of a batch in one pass
     for group in groups:
         nf = len(group)
         g_c = CsrGridder(geom, f_t[0].numel(), nf, device=dev)
@@ -189,7 +190,7 @@ def test_compact_kernel_matches_reference(rg, name):
             assert meta["weighting"] == "cressman"               # weights down to 0: no 26-bit code
             continue
         g_c.packed_stream = True
-        for tile in (0, 384):                                    # row-wise kernel (default), tile kernel over the records
+        for tile in ((0, 384) if nf <= 4 else (0,)):             # row-wise kernel (default), tile kernel over the records
             g_c.tile = tile
             got.fill_(-5.0)
             g_c.apply(got)

@@ -262,7 +262,7 @@ class TestNativeLibrary:
 
     def test_version_and_constants(self):
         lib = rg.load_library(require_device=False)
-        assert lib.rg_version() == _native.ABI_VERSION == 102
+        assert lib.rg_version() == _native.ABI_VERSION == 103
         header = open(os.path.join(REPO, "include", "radargrid_hip.h")).read()
         assert f"0x{_native.RG_EXCLUDED_BITS:08X}" in header.upper().replace("0X", "0x")
         assert np.isnan(np.array([_native.RG_EXCLUDED_BITS], dtype=np.uint32).view(np.float32)[0])
@@ -576,6 +576,7 @@ class TestCompactLayoutHostLogic:
         c.window_cap = 4096
         assert c.window_for(1) == 4096 and c.window_for(3) == 2688 and c.window_for(4) == 2048 and c.window_for(8) == 1024
         assert [c.entry_bytes(n) for n in (1, 2, 3, 4, 5, 8)] == [8, 8, 12, 16, 32, 32]      # 32 KiB of LDS
+        assert c.entry_bytes(8, rowwise=True) == 40 and c.entry_bytes(4, rowwise=True) == 16 and c.window_for(8, rowwise=True) == 768
         assert c.fallback_fraction(1000) == 0.0 and abs(c.fallback_fraction(850) - 0.7) < 1e-9
         assert abs(c.fallback_fraction(256) - 0.9) < 1e-9
 
