@@ -568,6 +568,15 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
 #endif
   constexpr bool kByteMask = rowwise_bytemask<NF>();       // window entries = (v' ..., byte mask): rg_compact_layout.hpp
   constexpr bool kNarrow = Cfg::narrow && !kByteMask, kRegs = REGS < 0 ? Cfg::regs : REGS != 0;
+  // Five fields and more (never the column mode): a row's sums do not travel to lane == row and wait there (2 * NF registers
+  // for the whole segment) -- when a round ends the L lanes of a row, which all hold all its sums after the butterfly, SHARE
+  // the fields: lane `sub` divides and stores fields sub, sub + L, ... (a select tree over the bits of sub picks them), so a
+  // store instruction writes L fields x 64 / L consecutive rows.  The same sums, the same division: the same bits.
+#if defined(RG_EXPERIMENTS) && defined(RG_ROWWISE_NO_SCATTER)
+  constexpr bool kScatter = false;
+#else
+  constexpr bool kScatter = NF >= 5 && !COLS;
+#endif
   // one field: the window holds (v', m) = (value, 1) of a gate, (0, 0) where it is excluded, so that a pair contributes
   // w * (v', m) -- the same float32 values as selecting on the EXCLUDED sentinel (w * 0 = +0, w * 1 = w) in two packed
   // instructions instead of a compare, two selects, a product and two adds
@@ -925,8 +934,11 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
               ap[k % KS][f] += w[i] * vv[f];
               aw[k % KSW][f] = __builtin_fmaf(w[i], g[f], aw[k % KSW][f]);
             }
-#if defined(RG_EXPERIMENTS) && defined(RG_ROWWISE_PAIR_FENCE)
-            if constexpr (NF >= 5) __builtin_amdgcn_sched_barrier(0);
+#if !(defined(RG_EXPERIMENTS) && defined(RG_ROWWISE_NO_PAIR_FENCE))
+            if constexpr (NF >= 5) {      // one pair at a time: its sums are complete before the next pair's window reads are issued
+#pragma unroll
+              for (int f = 0; f < NF; ++f) asm volatile("" : "+v"(ap[k % KS][f]), "+v"(aw[k % KSW][f]) : : "memory");
+            }
 #endif
             continue;
           } else if constexpr (kNarrow) {
@@ -970,7 +982,10 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
         }
         // the per-pair path of an over-wide chunk (rare): five fields and more take its pairs one at a time -- three 32-byte
         // gathers in flight per record would set the whole kernel's register count (167 instead of <= 128 for eight fields)
-        if constexpr (!kWindowed && NF >= 5) __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!kWindowed && NF >= 5) {
+#pragma unroll
+          for (int f = 0; f < NF; ++f) asm volatile("" : "+v"(ap[k % KS][f]), "+v"(aw[k % KSW][f]) : : "memory");
+        }
       }
     };
     // sums of step r's batch; `last`: the round ends here -> fold the row's lanes and hand the sums to the row
@@ -999,7 +1014,38 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
         sv[2 * f + 1] = sw;
       }
       rg::butterfly<2 * NF>(sv, nl);
-      if constexpr (kRegs) {      // every lane of a row holds the row's sums: lane == row fetches them
+      if constexpr (kScatter) {
+        float p[8], w[8];
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+          p[f] = f < NF ? sv[2 * f] : 0.0f;
+          w[f] = f < NF ? sv[2 * f + 1] : 0.0f;
+        }
+        // after s stages entry j holds field j * 2^s + (sub mod 2^s)
+        const int stages = lgl < 3 ? lgl : 3;                       // wave-uniform
+#pragma unroll
+        for (int st = 0; st < 3; ++st) {
+          if (st < stages) {
+            const bool bit = ((sub >> st) & 1) != 0;
+#pragma unroll
+            for (int i = 0; i < (8 >> (st + 1)); ++i) {
+              p[i] = bit ? p[2 * i + 1] : p[2 * i];
+              w[i] = bit ? w[2 * i + 1] : w[2 * i];
+            }
+          }
+        }
+        const int lp = 1 << stages;                                 // fields a row's lanes share among themselves
+        const int f0 = sub & (lp - 1);
+        const bool owner = r.live && (sub >> stages) == 0;          // more than 8 lanes per row: the first 8 store
+        float* dst = out + ((size_t)f0 * n_vox + r0 + r.myrow);
+        const size_t step_f = (size_t)lp * n_vox;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (j < (8 >> stages)) {                                  // wave-uniform
+            if (owner && f0 + j * lp < NF) dst[j * step_f] = w[j] > 0.0f ? p[j] / w[j] : fill;
+          }
+        }
+      } else if constexpr (kRegs) {      // every lane of a row holds the row's sums: lane == row fetches them
         const int first = r.myrow - rgrp;                   // the round's first row (wave-uniform)
         const bool take = lane >= first && lane < first + rpr;
         const int src = ((lane - first) << lgl) & 63;
@@ -1058,7 +1104,7 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-  if (lane < nrows) {
+  if (lane < nrows && !(kScatter && span > 0)) {     // kScatter: the rounds stored their rows; a segment without pairs has none
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
       f32x2 s = (f32x2)(0.0f);
