@@ -185,11 +185,14 @@ template <> struct RowwiseConfig<8> { static constexpr int kpre = RG_ROWWISE_KPR
 // same float32 as adding w or +0) instead of compare + select + v_mul_legacy_f32 + two half packed adds -- the same bits from
 // fewer instructions.  Three fields: the mask word is the entry's fourth slot (16-byte entries); four fields: a second array of
 // words behind the 16-byte value entries; five to eight fields: 32-byte value entries and two mask words per entry behind them.
-// Five fields and more always use it; RG_ROWWISE_BYTEMASK = the smallest field count of 3 / 4 that does (5 = neither: measured
-// equal in time on the bench grid and config 2, EXPERIMENTS.md R4.5d, so three and four fields keep the 12- / 16-byte entries).
+// Measured with the pairs of a record taken one at a time (the asm fences of the kernel; without them the wider entries
+// cost a wavefront per SIMD and the gain): three / four fields -4 ... -5 % on the bench grid, -1 ... -4 % on config 2
+// (19 % fewer VALU instructions: profiles/r04_bytemask_*.json); five fields and more have no other form.
+// RG_ROWWISE_BYTEMASK = the smallest field count that uses it (experiment builds: 5 = the select + legacy-multiply form
+// for three and four fields).
 #if !defined(RG_EXPERIMENTS) || !defined(RG_ROWWISE_BYTEMASK)
 #undef RG_ROWWISE_BYTEMASK
-#define RG_ROWWISE_BYTEMASK 5
+#define RG_ROWWISE_BYTEMASK 3
 #endif
 template <int NF> constexpr bool rowwise_bytemask() { return NF >= 5 || (NF >= 3 && NF >= RG_ROWWISE_BYTEMASK); }
 // 4-byte words of LDS per window entry of the row-wise kernel: values, then masks

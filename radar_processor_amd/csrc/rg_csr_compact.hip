@@ -572,10 +572,12 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
   // for the whole segment) -- when a round ends the L lanes of a row, which all hold all its sums after the butterfly, SHARE
   // the fields: lane `sub` divides and stores fields sub, sub + L, ... (a select tree over the bits of sub picks them), so a
   // store instruction writes L fields x 64 / L consecutive rows.  The same sums, the same division: the same bits.
-#if defined(RG_EXPERIMENTS) && defined(RG_ROWWISE_NO_SCATTER)
-  constexpr bool kScatter = false;
+#if defined(RG_EXPERIMENTS) && defined(RG_ROWWISE_SCATTER_MIN_NF)
+  constexpr bool kScatter = NF >= RG_ROWWISE_SCATTER_MIN_NF && !COLS;
+  constexpr int kFenceMinNF = RG_ROWWISE_FENCE_MIN_NF;
 #else
-  constexpr bool kScatter = NF >= 5 && !COLS;
+  constexpr bool kScatter = NF >= 5 && !COLS;        // three / four fields: measured slower (stores of 16 rows x 4 fields)
+  constexpr int kFenceMinNF = 3;
 #endif
   // one field: the window holds (v', m) = (value, 1) of a gate, (0, 0) where it is excluded, so that a pair contributes
   // w * (v', m) -- the same float32 values as selecting on the EXCLUDED sentinel (w * 0 = +0, w * 1 = w) in two packed
@@ -935,7 +937,7 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
               aw[k % KSW][f] = __builtin_fmaf(w[i], g[f], aw[k % KSW][f]);
             }
 #if !(defined(RG_EXPERIMENTS) && defined(RG_ROWWISE_NO_PAIR_FENCE))
-            if constexpr (NF >= 5) {      // one pair at a time: its sums are complete before the next pair's window reads are issued
+            if constexpr (NF >= kFenceMinNF) {      // one pair at a time: its sums are complete before the next pair's window reads are issued
 #pragma unroll
               for (int f = 0; f < NF; ++f) asm volatile("" : "+v"(ap[k % KS][f]), "+v"(aw[k % KSW][f]) : : "memory");
             }
@@ -982,7 +984,7 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
         }
         // the per-pair path of an over-wide chunk (rare): five fields and more take its pairs one at a time -- three 32-byte
         // gathers in flight per record would set the whole kernel's register count (167 instead of <= 128 for eight fields)
-        if constexpr (!kWindowed && NF >= 5) {
+        if constexpr (NF >= kFenceMinNF) {
 #pragma unroll
           for (int f = 0; f < NF; ++f) asm volatile("" : "+v"(ap[k % KS][f]), "+v"(aw[k % KSW][f]) : : "memory");
         }
@@ -1015,20 +1017,21 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
       }
       rg::butterfly<2 * NF>(sv, nl);
       if constexpr (kScatter) {
-        float p[8], w[8];
+        constexpr int NP = NF <= 2 ? 2 : NF <= 4 ? 4 : 8, LGP = NF <= 2 ? 1 : NF <= 4 ? 2 : 3;    // fields, padded to 2^LGP
+        float p[NP], w[NP];
 #pragma unroll
-        for (int f = 0; f < 8; ++f) {
-          p[f] = f < NF ? sv[2 * f] : 0.0f;
-          w[f] = f < NF ? sv[2 * f + 1] : 0.0f;
+        for (int f = 0; f < NP; ++f) {
+          p[f] = f < NF ? sv[2 * (f < NF ? f : 0)] : 0.0f;
+          w[f] = f < NF ? sv[2 * (f < NF ? f : 0) + 1] : 0.0f;
         }
         // after s stages entry j holds field j * 2^s + (sub mod 2^s)
-        const int stages = lgl < 3 ? lgl : 3;                       // wave-uniform
+        const int stages = lgl < LGP ? lgl : LGP;                   // wave-uniform
 #pragma unroll
-        for (int st = 0; st < 3; ++st) {
+        for (int st = 0; st < LGP; ++st) {
           if (st < stages) {
             const bool bit = ((sub >> st) & 1) != 0;
 #pragma unroll
-            for (int i = 0; i < (8 >> (st + 1)); ++i) {
+            for (int i = 0; i < (NP >> (st + 1)); ++i) {
               p[i] = bit ? p[2 * i + 1] : p[2 * i];
               w[i] = bit ? w[2 * i + 1] : w[2 * i];
             }
@@ -1036,12 +1039,12 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
         }
         const int lp = 1 << stages;                                 // fields a row's lanes share among themselves
         const int f0 = sub & (lp - 1);
-        const bool owner = r.live && (sub >> stages) == 0;          // more than 8 lanes per row: the first 8 store
+        const bool owner = r.live && (sub >> stages) == 0;          // more lanes per row than (padded) fields: the first store
         float* dst = out + ((size_t)f0 * n_vox + r0 + r.myrow);
         const size_t step_f = (size_t)lp * n_vox;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          if (j < (8 >> stages)) {                                  // wave-uniform
+        for (int j = 0; j < NP; ++j) {
+          if (j < (NP >> stages)) {                                 // wave-uniform
             if (owner && f0 + j * lp < NF) dst[j * step_f] = w[j] > 0.0f ? p[j] / w[j] : fill;
           }
         }

@@ -208,16 +208,22 @@ class CompactCSR:
 
     @staticmethod
     def entry_bytes(n_fields: int, rowwise: bool = False) -> int:
-        """Bytes of one LDS window entry of the compact kernels: the packed slots of a gate (2, 4 or 8 floats), a 3-field
-        entry without its padding slot; one field: the value and a 0/1 factor (row-wise kernel; the tile kernel keeps the
-        value alone); 5-8 fields through the row-wise kernel (``rowwise``): 8 values + 8 mask bytes."""
+        """Bytes of one LDS window entry of the compact kernels.  Tile kernels: the packed slots of a gate (1, 2, 4 or 8
+        floats; a 3-field entry without its padding slot).  Row-wise kernel (``rowwise``): one field the value and a 0/1
+        factor, two fields the two values, three and more the values (v' = value or +0) plus one mask byte per field -- 16,
+        20 and 40 bytes for 3, 4 and 5-8 fields (``csrc/rg_compact_layout.hpp``: rowwise_entry_words)."""
+        if rowwise and n_fields >= 3:
+            return 16 if n_fields == 3 else 20 if n_fields == 4 else 40
         if n_fields > 4:
-            return 40 if rowwise else 32
+            return 32
         return 4 * (2 if n_fields <= 2 else 3 if n_fields == 3 else 4)
 
-    def window_for(self, n_fields: int, lds_budget_bytes: int = 32768, rowwise: bool = False) -> int:
+    def window_for(self, n_fields: int, lds_budget_bytes: Optional[int] = None, rowwise: bool = False) -> int:
         """LDS window (entries) for a pass of ``n_fields`` fields: the geometry's 99.9 % window if its entries fit
-        ``lds_budget_bytes``, else the largest that does."""
+        ``lds_budget_bytes`` (default 32 KiB; 48 KiB for the row-wise kernel's 3-8 field entries, which carry mask bytes and
+        have no tile next to them), else the largest that does."""
+        if lds_budget_bytes is None:
+            lds_budget_bytes = 49152 if (rowwise and n_fields >= 3) else 32768
         room = max(0, lds_budget_bytes // self.entry_bytes(n_fields, rowwise)) // 64 * 64
         return int(min(self.window_cap, room))
 

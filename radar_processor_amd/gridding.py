@@ -367,7 +367,7 @@ def _fields_per_pass(geometry: GridGeometry, dev, use_compact: bool) -> int:
         if compact is not None and not compact.ensure_packed(csr):
             compact = None
     if compact is not None:
-        return 8 if compact.window_for(8, rowwise=True) >= compact.window_cap else 4
+        return 8 if compact.window_cap * compact.entry_bytes(8, rowwise=True) <= 32768 else 4    # 5 workgroups per CU
     return _native.RG_MAX_FIELDS
 
 

@@ -576,7 +576,8 @@ class TestCompactLayoutHostLogic:
         c.window_cap = 4096
         assert c.window_for(1) == 4096 and c.window_for(3) == 2688 and c.window_for(4) == 2048 and c.window_for(8) == 1024
         assert [c.entry_bytes(n) for n in (1, 2, 3, 4, 5, 8)] == [8, 8, 12, 16, 32, 32]      # 32 KiB of LDS
-        assert c.entry_bytes(8, rowwise=True) == 40 and c.entry_bytes(4, rowwise=True) == 16 and c.window_for(8, rowwise=True) == 768
+        assert [c.entry_bytes(n, rowwise=True) for n in (1, 2, 3, 4, 5, 8)] == [8, 8, 16, 20, 40, 40]
+        assert c.window_for(8, rowwise=True) == 1216 and c.window_for(3, rowwise=True) == 3072 and c.window_for(4, rowwise=True) == 2432
         assert c.fallback_fraction(1000) == 0.0 and abs(c.fallback_fraction(850) - 0.7) < 1e-9
         assert abs(c.fallback_fraction(256) - 0.9) < 1e-9
 
