@@ -860,17 +860,46 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
 #else
     constexpr int KSW = NF >= 5 ? 1 : KS;
 #endif
-    float ap[KS][NF], aw[KSW][NF];
+    // Byte-mask kernels keep the sums of field PAIRS in 64-bit register pairs (bp / bw: what v_pk_mul / v_pk_add / v_pk_fma
+    // take, and what the per-pair asm fences can name without splitting the pairs); the others keep scalars the compiler pairs.
+    constexpr int NP2 = (NF + 1) / 2;
+    float ap[kByteMask ? 1 : KS][kByteMask ? 1 : NF], aw[kByteMask ? 1 : KSW][kByteMask ? 1 : NF];
+    f32x2 bp[kByteMask ? KS : 1][kByteMask ? NP2 : 1], bw[kByteMask ? KSW : 1][kByteMask ? NP2 : 1];
 #pragma unroll
-    for (int k = 0; k < KS; ++k) {
+    for (int k = 0; k < (kByteMask ? 1 : KS); ++k) {
 #pragma unroll
-      for (int f = 0; f < NF; ++f) ap[k][f] = 0.0f;
+      for (int f = 0; f < (kByteMask ? 1 : NF); ++f) ap[k][f] = 0.0f;
     }
 #pragma unroll
-    for (int k = 0; k < KSW; ++k) {
+    for (int k = 0; k < (kByteMask ? 1 : KSW); ++k) {
 #pragma unroll
-      for (int f = 0; f < NF; ++f) aw[k][f] = 0.0f;
+      for (int f = 0; f < (kByteMask ? 1 : NF); ++f) aw[k][f] = 0.0f;
     }
+#pragma unroll
+    for (int k = 0; k < (kByteMask ? KS : 1); ++k) {
+#pragma unroll
+      for (int j = 0; j < (kByteMask ? NP2 : 1); ++j) bp[k][j] = (f32x2)(0.0f);
+    }
+#pragma unroll
+    for (int k = 0; k < (kByteMask ? KSW : 1); ++k) {
+#pragma unroll
+      for (int j = 0; j < (kByteMask ? NP2 : 1); ++j) bw[k][j] = (f32x2)(0.0f);
+    }
+    auto addp = [&](int k, int f, float x) {          // k, f compile-time after unrolling
+      if constexpr (kByteMask) bp[k][f >> 1][f & 1] += x; else ap[k][f] += x;
+    };
+    auto addw = [&](int k, int f, float x) {
+      if constexpr (kByteMask) bw[k][f >> 1][f & 1] += x; else aw[k][f] += x;
+    };
+    auto fence_sums = [&](int kp, int kw) {           // everything added so far is complete; no memory access moves across
+      if constexpr (kByteMask) {
+#pragma unroll
+        for (int j = 0; j < NP2; ++j) asm volatile("" : "+v"(bp[kp][j]), "+v"(bw[kw][j]) : : "memory");
+      } else {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) asm volatile("" : "+v"(ap[kp][f]), "+v"(aw[kw][f]) : : "memory");
+      }
+    };
     auto consume = [&](const Step& r, const rg_u32x4& q4, int k) {     // k: slot of the step's batch (compile-time)
       // the record's pairs i = 0, 1, 2 belong to the lane's row iff lo <= i < lo + len (len = 0 for a lane without record)
       const int lo = r.lo0 - 3 * (k << lgl);
@@ -911,38 +940,26 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
               const uint2 mm = reinterpret_cast<const uint2*>(maskw)[e];
               m[0] = mm.x; m[1] = mm.y;
             }
-            float g[8];
+            using g2_t = decltype(__builtin_amdgcn_cvt_pk_f32_fp8(0, false));
+            f32x2 g2[4];
             if constexpr (kMaskFp8) {      // one conversion per field PAIR: v_cvt_pk_f32_fp8 (OCP e4m3: 0x38 = 1.0, 0x00 = +0)
-              const auto g01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)m[0], false);
-              g[0] = g01[0]; g[1] = g01[1];
-              if constexpr (NF > 2) {
-                const auto g23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)m[0], true);
-                g[2] = g23[0]; g[3] = g23[1];
-              }
-              if constexpr (NF > 4) {
-                const auto g45 = __builtin_amdgcn_cvt_pk_f32_fp8((int)m[1], false);
-                g[4] = g45[0]; g[5] = g45[1];
-              }
-              if constexpr (NF > 6) {
-                const auto g67 = __builtin_amdgcn_cvt_pk_f32_fp8((int)m[1], true);
-                g[6] = g67[0]; g[7] = g67[1];
-              }
+              const g2_t a = __builtin_amdgcn_cvt_pk_f32_fp8((int)m[0], false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)m[0], true);
+              const g2_t c = __builtin_amdgcn_cvt_pk_f32_fp8((int)m[1], false), d = __builtin_amdgcn_cvt_pk_f32_fp8((int)m[1], true);
+              g2[0] = (f32x2){a[0], a[1]}; g2[1] = (f32x2){b[0], b[1]}; g2[2] = (f32x2){c[0], c[1]}; g2[3] = (f32x2){d[0], d[1]};
             } else {
 #pragma unroll
-              for (int f = 0; f < NF; ++f) g[f] = (float)((m[f >> 2] >> (8 * (f & 3))) & 0xFFu);
+              for (int j = 0; j < 4; ++j)
+                g2[j] = (f32x2){(float)((m[j >> 1] >> (16 * (j & 1))) & 0xFFu), (float)((m[j >> 1] >> (16 * (j & 1) + 8)) & 0xFFu)};
             }
+            const f32x2 w2 = (f32x2){w[i], w[i]};
 #pragma unroll
-            for (int f = 0; f < NF; ++f) {
-              ap[k % KS][f] += w[i] * vv[f];
-              aw[k % KSW][f] = __builtin_fmaf(w[i], g[f], aw[k % KSW][f]);
+            for (int j = 0; j < NP2; ++j) {
+              const f32x2 prod = w2 * (f32x2){vv[2 * j], vv[2 * j + 1]};       // float32 product, then the add (no contraction)
+              bp[k % KS][j] += prod;
+              bw[k % KSW][j] = __builtin_elementwise_fma(w2, g2[j], bw[k % KSW][j]);
             }
-#if !(defined(RG_EXPERIMENTS) && defined(RG_ROWWISE_NO_PAIR_FENCE))
-            if constexpr (NF >= kFenceMinNF) {      // one pair at a time: its sums are complete before the next pair's window reads are issued
-#pragma unroll
-              for (int f = 0; f < NF; ++f) asm volatile("" : "+v"(ap[k % KS][f]), "+v"(aw[k % KSW][f]) : : "memory");
-            }
-#endif
-            continue;
+            if constexpr (NF >= kFenceMinNF) fence_sums(k % KS, k % KSW);   // one pair at a time: these sums are complete
+            continue;                                                       // before the next pair's window reads are issued
           } else if constexpr (kNarrow) {
             v[0] = window[e * 3]; v[1] = window[e * 3 + 1]; v[2] = window[e * 3 + 2];
           } else if constexpr (kPremask) {
@@ -974,20 +991,17 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
           // where an IEEE multiply would make NaN (for a non-zero weight the two multiplies are the same operation, so
           // unmasked NaN / Inf data propagates exactly as before: same bits as good ? w * v : 0)
 #if defined(RG_EXPERIMENTS) && defined(RG_ROWWISE_TWO_SELECTS)   // A/B builds only: round 2's form of the same arithmetic
-          ap[k % KS][f] += good ? w[i] * v[f] : 0.0f;
-          aw[k % KSW][f] += good ? w[i] : 0.0f;
+          addp(k % KS, f, good ? w[i] * v[f] : 0.0f);
+          addw(k % KSW, f, good ? w[i] : 0.0f);
 #else
           const float wf = good ? w[i] : 0.0f;
-          ap[k % KS][f] += rg_fmul_legacy(wf, v[f]);
-          aw[k % KSW][f] += wf;
+          addp(k % KS, f, rg_fmul_legacy(wf, v[f]));
+          addw(k % KSW, f, wf);
 #endif
         }
         // the per-pair path of an over-wide chunk (rare): five fields and more take its pairs one at a time -- three 32-byte
         // gathers in flight per record would set the whole kernel's register count (167 instead of <= 128 for eight fields)
-        if constexpr (NF >= kFenceMinNF) {
-#pragma unroll
-          for (int f = 0; f < NF; ++f) asm volatile("" : "+v"(ap[k % KS][f]), "+v"(aw[k % KSW][f]) : : "memory");
-        }
+        if constexpr (NF >= kFenceMinNF) fence_sums(k % KS, k % KSW);
       }
     };
     // sums of step r's batch; `last`: the round ends here -> fold the row's lanes and hand the sums to the row
@@ -1000,20 +1014,43 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
       float sv[2 * NF];
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
-        float sp = ap[0][f], sw = aw[0][f];           // chains in ascending order
-        ap[0][f] = aw[0][f] = 0.0f;
+        float sp, sw;                                  // chains in ascending order
+        if constexpr (kByteMask) {
+          sp = bp[0][f >> 1][f & 1];
+          sw = bw[0][f >> 1][f & 1];
 #pragma unroll
-        for (int k = 1; k < KS; ++k) {
-          sp += ap[k][f];
-          ap[k][f] = 0.0f;
-        }
+          for (int k = 1; k < KS; ++k) sp += bp[k][f >> 1][f & 1];
 #pragma unroll
-        for (int k = 1; k < KSW; ++k) {
-          sw += aw[k][f];
-          aw[k][f] = 0.0f;
+          for (int k = 1; k < KSW; ++k) sw += bw[k][f >> 1][f & 1];
+        } else {
+          sp = ap[0][f];
+          sw = aw[0][f];
+          ap[0][f] = aw[0][f] = 0.0f;
+#pragma unroll
+          for (int k = 1; k < KS; ++k) {
+            sp += ap[k][f];
+            ap[k][f] = 0.0f;
+          }
+#pragma unroll
+          for (int k = 1; k < KSW; ++k) {
+            sw += aw[k][f];
+            aw[k][f] = 0.0f;
+          }
         }
         sv[2 * f] = sp;
         sv[2 * f + 1] = sw;
+      }
+      if constexpr (kByteMask) {
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+#pragma unroll
+          for (int j = 0; j < NP2; ++j) bp[k][j] = (f32x2)(0.0f);
+        }
+#pragma unroll
+        for (int k = 0; k < KSW; ++k) {
+#pragma unroll
+          for (int j = 0; j < NP2; ++j) bw[k][j] = (f32x2)(0.0f);
+        }
       }
       rg::butterfly<2 * NF>(sv, nl);
       if constexpr (kScatter) {
