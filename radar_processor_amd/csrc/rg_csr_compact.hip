@@ -935,10 +935,17 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
               vv[0] = x.x; vv[1] = x.y; vv[2] = x.z; vv[3] = x.w;
               m[0] = NF == 3 ? rg::f32_bits(x.w) : maskw[e];
             } else {
+              if constexpr (DIAG & 1024) {      // timing-only: no window reads
+                const float fe = __builtin_bit_cast(float, 0x3F800000u | (unsigned)e);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) vv[q] = fe;
+                m[0] = m[1] = 0x38383838u;
+              } else {
               const f32x4 x = reinterpret_cast<const f32x4*>(window)[2 * e], y = reinterpret_cast<const f32x4*>(window)[2 * e + 1];
               vv[0] = x.x; vv[1] = x.y; vv[2] = x.z; vv[3] = x.w; vv[4] = y.x; vv[5] = y.y; vv[6] = y.z; vv[7] = y.w;
               const uint2 mm = reinterpret_cast<const uint2*>(maskw)[e];
               m[0] = mm.x; m[1] = mm.y;
+              }
             }
             using g2_t = decltype(__builtin_amdgcn_cvt_pk_f32_fp8(0, false));
             f32x2 g2[4];
@@ -1082,7 +1089,11 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
           if (j < (NP >> stages)) {                                 // wave-uniform
-            if (owner && f0 + j * lp < NF) dst[j * step_f] = w[j] > 0.0f ? p[j] / w[j] : fill;
+            if constexpr (DIAG & 2) {      // timing-only: no output store
+              if (owner && f0 + j * lp < NF && p[j] == 123.456f) dst[j * step_f] = w[j];
+            } else {
+              if (owner && f0 + j * lp < NF) dst[j * step_f] = w[j] > 0.0f ? p[j] / w[j] : fill;
+            }
           }
         }
       } else if constexpr (kRegs) {      // every lane of a row holds the row's sums: lane == row fetches them
@@ -1297,6 +1308,19 @@ int launch_rowwise_nf(int nf, int window_cap, const void* indptr, const int64_t*
   if (lanes_hint >= 200 && lanes_hint <= 264) {                // tile = 2200 + n: n consecutive chunks per workgroup
     cpb = lanes_hint - 200;
     lanes_hint = 0;
+  }
+  if (nf == 8 && lanes_hint >= 100 && lanes_hint < 200) {      // eight fields, timing-only: 1 = no gather, 2 = no store, 16 = no
+    switch (lanes_hint - 100) {                                //   record loads, 40 = no window reads, 42 = 40 + 2, 19 = 16 + 2 + 1
+      case 1: return launch_rowwise<IndT, 8, 1>(window_cap, indptr, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s, ps, 0, 1);
+      case 2: return launch_rowwise<IndT, 8, 2>(window_cap, indptr, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s, ps, 0, 1);
+      case 16: return launch_rowwise<IndT, 8, 16>(window_cap, indptr, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s, ps, 0, 1);
+      case 19: return launch_rowwise<IndT, 8, 19>(window_cap, indptr, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s, ps, 0, 1);
+      case 40: return launch_rowwise<IndT, 8, 1024>(window_cap, indptr, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s, ps, 0, 1);
+      case 42: return launch_rowwise<IndT, 8, 1026>(window_cap, indptr, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s, ps, 0, 1);
+      case 43: return launch_rowwise<IndT, 8, 1027>(window_cap, indptr, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s, ps, 0, 1);
+      case 59: return launch_rowwise<IndT, 8, 1043>(window_cap, indptr, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s, ps, 0, 1);
+      default: break;
+    }
   }
   if (nf == 1 && lanes_hint >= 100 && lanes_hint < 200) {      // timing-only diagnostics (tile = 2100 + DIAG bits)
     const int cpb1 = 1;          // the diagnostics run one chunk per workgroup
