@@ -560,13 +560,15 @@ def run_rank(args):
             want_compact = free_b > 3.2 * geom.n_pairs() + (8 << 30)
         gridder = CsrGridder(geom, n_gates, fields_per_pass, device=dev, compact=want_compact)
         n_pairs = gridder.csr.n_pairs
-        settled = None
+        settled = settle_out = None
         torch.cuda.synchronize()
         t_built = time.perf_counter() - t0                       # the geometry itself; what follows is optional tuning
         if gridder.compact is not None and gridder.packed_stream and args.settle_tries > 1 and not args.tile_kernel:
             gridder.pack(fields_d[:fields_per_pass] if len(fields_d) >= fields_per_pass else (fields_d * fields_per_pass)[:fields_per_pass],
                          (masks_d[:fields_per_pass] if len(masks_d) >= fields_per_pass else (masks_d * fields_per_pass)[:fields_per_pass]))
-            settled = gridder.settle_records(tries=args.settle_tries)        # part of the one-off geometry build: untimed
+            # probed on the very grid the timed steps will write (the draw is about where records AND grid lie)
+            settle_out = None if c5 else torch.empty((n_ff, n_vox), dtype=torch.float32, device=dev)
+            settled = gridder.settle_records(tries=args.settle_tries, out=settle_out)   # part of the one-off geometry build: untimed
             if settled is not None:
                 torch.cuda.synchronize()
                 settled["seconds"] = round(time.perf_counter() - t0 - t_built, 3)
@@ -623,7 +625,7 @@ def run_rank(args):
             return vb.grid_shard(dev_volumes, products=c5_products, rank=rank, world_size=world,
                                  events=events if timed else None)
     else:
-        out = torch.empty((n_ff, n_vox), dtype=torch.float32, device=dev)
+        out = settle_out if (args.mode == "csr" and settle_out is not None) else torch.empty((n_ff, n_vox), dtype=torch.float32, device=dev)
         grid4 = out.view(n_ff, *shape)
 
         def step(timed=False):
