@@ -187,6 +187,36 @@ def test_rowwise_order_restatement_is_the_reference_mean(name):
             np.testing.assert_allclose(other, want, rtol=1e-5, atol=atol, equal_nan=True)
 
 
+@pytest.mark.parametrize("name", golden_names("g3_c2_r060")[:1] + golden_names("g2_")[:1])
+def test_rowwise_order_restatement_for_five_to_eight_fields(name):
+    """Passes of 5-8 fields (eight volumes of a batch in one pass): the restatement keeps ONE chain for the weight sums
+    (ROWWISE_WEIGHT_CHAINS) and the eight-field lane split; on the REFERENCE's CSR every field of such a pass still
+    reproduces the reference's grid within the bar, equals a single-field pass of the same lane split / batch / chain
+    counts bit for bit, and differs from the two-chain form only in float32 rounding."""
+    meta, ref = load_golden(name)
+    vol = volume_for(meta)
+    shape, _ = grid_spec(meta)
+    idx = reference_indices(name, meta, ref)
+    base = [oracle.merge_masks(vol.fields[f]) for f in meta["fields"]]
+    for nf in (5, 8):
+        pairs = [base[i % len(base)] for i in range(nf)]
+        data, masks = [p[0] for p in pairs], [p[1] for p in pairs]
+        assert oracle.ROWWISE_WEIGHT_CHAINS[nf] == 1 and oracle.ROWWISE_KPRE[nf] == 3
+        fused = oracle.csr_apply_rowwise_order(ref["indptr"], idx, ref["weights"], data, masks, shape)
+        two = oracle.csr_apply_rowwise_order(ref["indptr"], idx, ref["weights"], data, masks, shape, weight_chains=2)
+        for k in range(nf):
+            fname = meta["fields"][k % len(base)]
+            want = ref[f"grid_{fname}"]
+            atol = 1e-5 * float(np.nanmax(np.abs(data[k][~masks[k]])))
+            np.testing.assert_array_equal(np.isnan(fused[k]), np.isnan(want))
+            np.testing.assert_allclose(fused[k], want, rtol=1e-5, atol=atol, equal_nan=True)
+            np.testing.assert_allclose(fused[k], two[k], rtol=2e-6, atol=atol, equal_nan=True)
+        single = oracle.csr_apply_rowwise_order(ref["indptr"], idx, ref["weights"], data[1:2], masks[1:2], shape,
+                                                lanes_hint=70 + oracle.ROWWISE_TARGET[nf], kpre=oracle.ROWWISE_KPRE[nf],
+                                                weight_chains=1)[0]
+        np.testing.assert_array_equal(single, fused[1])
+
+
 def test_rowwise_order_restatement_known_answers():
     """The reference's unit-test answers (test_radar_grid_interpolate.py:75-93, :236-277, :116-153) through the restatement."""
     def run(indptr, idx, w, values, fill=np.nan):

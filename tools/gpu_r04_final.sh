@@ -9,7 +9,7 @@ python3 -c "from radar_processor_amd import build; assert not build.is_stale(), 
 timeout -k 10 1000 python3 -m pytest tests -m gpu -x -q > gpurun_out/${T}_tests.log 2>&1
 rc=$?; tail -4 gpurun_out/${T}_tests.log; [ $rc -eq 0 ] || exit $rc
 timeout -k 10 500 python3 bench.py > gpurun_out/${T}_default.json 2> gpurun_out/${T}_default.log || { tail -20 gpurun_out/${T}_default.log; exit 1; }
-for i in 1 2 3 4 5 6; do
+for i in 1 2 3; do
   timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-c5-extra > gpurun_out/${T}_var_$i.json 2> gpurun_out/${T}_var_$i.log || exit 1
 done
 timeout -k 10 300 python3 bench.py --layout csr --no-cpu-baseline --no-c5-extra > gpurun_out/${T}_csrlayout.json 2> gpurun_out/${T}_csrlayout.log
@@ -20,6 +20,7 @@ timeout -k 10 300 python3 bench.py --config C2 --fields 3 --no-cpu-baseline --no
 timeout -k 10 300 python3 bench.py --fields 3 --no-cpu-baseline --no-c5-extra --steps 10 > gpurun_out/${T}_m3.json 2> gpurun_out/${T}_m3.log
 timeout -k 10 400 python3 bench.py --config C4 --no-cpu-baseline --steps 5 --warmup 1 > gpurun_out/${T}_c4.json 2> gpurun_out/${T}_c4.log
 timeout -k 10 300 python3 bench.py --config C5 --no-cpu-baseline --steps 5 --warmup 1 > gpurun_out/${T}_c5.json 2> gpurun_out/${T}_c5.log
+timeout -k 10 300 python3 bench.py --config C5 --c5-per-pass 4 --no-cpu-baseline --steps 5 --warmup 1 > gpurun_out/${T}_c5p4.json 2> gpurun_out/${T}_c5p4.log
 timeout -k 10 300 python3 bench.py --config C5 --products fused --no-cpu-baseline --steps 5 --warmup 1 > gpurun_out/${T}_c5fused.json 2> gpurun_out/${T}_c5fused.log
 timeout -k 10 300 python3 bench.py --config C5 --mode fused --no-cpu-baseline --steps 5 --warmup 1 > gpurun_out/${T}_c5k2.json 2> gpurun_out/${T}_c5k2.log
 timeout -k 10 300 python3 bench.py --mode fused --no-cpu-baseline --no-c5-extra --steps 5 > gpurun_out/${T}_k2.json 2> gpurun_out/${T}_k2.log
@@ -28,7 +29,7 @@ python3 - "$T" <<'PY'
 import json, sys
 t = sys.argv[1]
 rows = {}
-for f in ["default"] + [f"var_{i}" for i in range(1, 7)] + ["csrlayout", "tile", "k1", "c2", "c3", "m3", "c4", "c5", "c5fused", "c5k2", "k2", "c4k2"]:
+for f in ["default"] + [f"var_{i}" for i in range(1, 4)] + ["csrlayout", "tile", "k1", "c2", "c3", "m3", "c4", "c5", "c5p4", "c5fused", "c5k2", "k2", "c4k2"]:
     try:
         d = json.load(open(f"gpurun_out/{t}_{f}.json")); r = d["roofline"]; e = d.get("extras", {})
         rows[f] = d
