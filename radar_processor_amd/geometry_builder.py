@@ -327,7 +327,7 @@ def compute_grid_geometry(
         raise ValueError("layout must be 'csr', 'compact', 'packed' or 'auto'")
     if layout == "auto":
         # Large geometries whose weights fit the 26-bit code (Barnes, uniform) are built in the packed layout ALONE: row
-        # pointers + dictionaries + 16-byte records, 5.4 bytes per pair -- it is what every gridding pass of 1-4 fields reads
+        # pointers + dictionaries + 16-byte records, 5.4 bytes per pair -- it is what every gridding pass of 1-8 fields reads
         # anyway, the reference's index and weight arrays are rebuilt from it on demand, bit for bit (CompactCSR.decode /
         # decode_weights: save_geometry, the CPU baseline, the bench's post-check), and a process touches 47 GB instead of
         # 115 GB for the bench geometry (first-touch allocation is what a build's wall time consists of).  Geometries below

@@ -70,7 +70,7 @@ class CompactCSR:
         self.grid_shape = tuple(int(v) for v in grid_shape)   # (planes, lines per plane, rows per line)
         self.chunk_pairs = chunk_pairs      # int64 [chunks]: pairs per chunk    } kept to choose the window for a
         self.chunk_counts = chunk_counts    # int64 [chunks]: distinct gates     } given field count (window_for)
-        # packed pair stream for passes of 1-4 fields (ensure_packed): 16-byte records of three pairs, or None
+        # packed pair stream for passes of 1-8 fields (ensure_packed): 16-byte records of three pairs, or None
         self.rec = None                     # int32 [n_rec, 4]
         self.rec_ptr = None                 # int64 [slots + 1]: records of the segment in slot s (see rec_order)
         self.rec_order = DEFAULT_REC_ORDER  # RG_REC_ORDER_SEGMENT (slot = segment) / RG_REC_ORDER_DISPATCH (slot_of_segments)

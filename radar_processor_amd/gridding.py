@@ -76,7 +76,7 @@ class CsrGridder:
         """``compact``: run the pass through the compact device copy of the CSR (built and cached on the geometry the
         first time) when the geometry allows one and its LDS window for this field count covers (nearly) all pairs:
         ``rg_csr_compact_apply_packed_f32`` (row-wise kernel over the packed records; agrees with ``rg_csr_apply_f32`` to
-        float32 rounding) for 1-4 fields when the weights are codable and ``packed`` is set, ``rg_csr_compact_apply_f32``
+        float32 rounding) for 1-8 fields when the weights are codable and ``packed`` is set, ``rg_csr_compact_apply_f32``
         (tile kernel; agrees bit for bit) otherwise.  ``tile``: diagnostic override -- 128...512 the pipeline tile of the
         tile kernels (non-default values change the order of the float32 adds), 384 also selects the tile kernel over
         the packed records, 2000 + h the lane split of the row-wise kernel."""
@@ -104,9 +104,9 @@ class CsrGridder:
         #                              1 field        2 fields       3 fields       4 fields       8 fields
         #   rg_csr_apply_f32           1.9 / 13.1     2.1 / 14.7     2.3 / 16.5     3.0 / 20.5     7.3 / 49.8
         #   compact, tile kernel       1.11 / 8.4     1.69 / 11.6    2.2 / 14.6     3.3 / 19.5     9.6 / 65
-        #   compact, row-wise kernel   1.02 / 7.9     1.13 / 8.7     1.29 / 10.1    1.50 / 11.4    (1-4 fields only)
+        #   compact, row-wise kernel   1.02 / 7.9     1.13 / 8.7     1.29 / 10.1    1.47 / 10.3    3.9 / 14.4
         # The row-wise kernel reads the packed records (weights codable in 26 bits: Barnes, nearest) and has no tile in
-        # LDS, so it wins at every window it can hold.  The tile kernel (weights not codable, or 5-8 fields) wins while its
+        # LDS, so it wins at every window it can hold.  The tile kernel (weights not codable) wins while its
         # window stays <= 24 KiB next to its tiles and loses beyond; a compact-only geometry has no choice.
         want = compact or compact_only
         self.compact = geometry.device_compact(self.dev) if (want and self.csr.n_pairs) else None
@@ -118,7 +118,7 @@ class CsrGridder:
                 # too many chunks would gather per pair (dense scans next to many fields): the standard kernel is faster
                 self.compact, self.window = None, 0
         if self.compact is not None:
-            # passes of 1-4 fields stream the packed records (positions + weights, 5.33 bytes per pair) when the geometry's
+            # passes of 1-8 fields stream the packed records (positions + weights, 5.33 bytes per pair) when the geometry's
             # weights allow the lossless 26-bit code and the memory is there
             self.packed_stream = bool((packed or packed_only) and self.compact.ensure_packed(self.csr))
             if self.packed_stream:

@@ -34,7 +34,7 @@ class VolumePipeline:
         self.dev = _native.canonical_device(device)
         self.geometry = geometry
         # compact=True: pipelines over a large geometry grid through its compact CSR copy (the same values to float32
-        # rounding: passes of 1-4 fields run the row-wise kernel over the packed records)
+        # rounding: passes of 1-8 fields run the row-wise kernel over the packed records)
         self.gridder = CsrGridder(geometry, n_gates, n_fields, device=self.dev, compact=compact)
         self.n_fields, self.n_gates = int(n_fields), int(n_gates)
         self.fill_value = fill_value
