@@ -673,7 +673,9 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
     rec_b = rec_ptr[slot];
     rec_n = rec_ptr[slot + 1] - rec_b;
   }
-  const rsrc_t rr = make_rsrc(rec + rec_b, rec_n * 16);
+  // DIAG & 2048 (timing-only): every segment reads its records 1/7 closer to the array's start, so that neighbours' streams
+  // overlap by a seventh -- the same loads, 14 % fewer distinct bytes from HBM (what a 4.57-byte-per-pair record would stream)
+  const rsrc_t rr = make_rsrc(rec + ((DIAG & 2048) ? rec_b * 6 / 7 : rec_b), rec_n * 16);
   constexpr int kOutOfRange = 0x7FFFFFF0;            // byte offset no segment reaches: the load returns zeros
 
   // ---- lanes per row ------------------------------------------------------------------------------------------
@@ -1332,6 +1334,7 @@ int launch_rowwise_nf(int nf, int window_cap, const void* indptr, const int64_t*
       case 70: return launch_rowwise<IndT, 1, 128>(window_cap, indptr, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s, ps, 0, cpb1);
       case 71: return launch_rowwise<IndT, 1, 256>(window_cap, indptr, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s, ps, 0, cpb1);
       case 72: return launch_rowwise<IndT, 1, 512>(window_cap, indptr, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s, ps, 0, cpb1);
+      case 73: return launch_rowwise<IndT, 1, 2048>(window_cap, indptr, dict_ptr, dict, cg, n_vox, packed, n_gates, fill, out, s, ps, 0, cpb1);
       default: break;
     }
 #undef RG_DIAG
