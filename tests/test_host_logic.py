@@ -432,6 +432,12 @@ class TestNativeLibrary:
         with pytest.raises(rg.NativeUnavailable):
             rg.compute_grid_geometry(np.zeros(4, np.float32), np.zeros(4, np.float32), np.zeros(4, np.float32), (1, 2, 2),
                                      ((0.0, 0.0), (0.0, 1.0), (0.0, 1.0)), ".", layout="compact")
+        # asking how many fields a pass over this geometry fuses is a question about its DEVICE copy: no CPU answer
+        from radar_processor_amd import batch, gridding
+        with pytest.raises(rg.NativeUnavailable):
+            gridding.fields_per_pass(geometry)
+        with pytest.raises(rg.NativeUnavailable):
+            batch.VolumeBatch(geometry, ["DBZH"]).volumes_per_pass
 
     def test_product_package_never_imports_the_oracle(self):
         pkg_dir = os.path.dirname(rg.__file__)
