@@ -570,8 +570,9 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
   constexpr bool kNarrow = Cfg::narrow && !kByteMask, kRegs = REGS < 0 ? Cfg::regs : REGS != 0;
   // Five fields and more (never the column mode): a row's sums do not travel to lane == row and wait there (2 * NF registers
   // for the whole segment) -- when a round ends the L lanes of a row, which all hold all its sums after the butterfly, SHARE
-  // the fields: lane `sub` divides and stores fields sub, sub + L, ... (a select tree over the bits of sub picks them), so a
-  // store instruction writes L fields x 64 / L consecutive rows.  The same sums, the same division: the same bits.
+  // the fields: lane `sub` divides fields sub, sub + L, ... (a select tree over the bits of sub picks them) and parks the VALUES
+  // in 2 KiB of LDS per wavefront; lane == row stores them as whole row runs when the segment ends (storing per round wrote 16-32-row
+  // pieces: 1.37x the grid's bytes in partial lines, +1.4 %).  The same sums, the same division: the same bits.
 #if defined(RG_EXPERIMENTS) && defined(RG_ROWWISE_SCATTER_MIN_NF)
   constexpr bool kScatter = NF >= RG_ROWWISE_SCATTER_MIN_NF && !COLS;
   constexpr int kFenceMinNF = RG_ROWWISE_FENCE_MIN_NF;
@@ -597,9 +598,19 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
   (void)kMW;
   unsigned* const maskw = reinterpret_cast<unsigned*>(window + (size_t)(window_cap + 1) * kVW);
   __shared__ f32x2 rowacc_all[kRegs ? 1 : kH][kRegs ? 2 : 64 * NF];
+  // kScatter with kStage: the finished values of a segment wait in LDS ([row][8 fields], 2 KiB per wavefront) so that lane == row
+  // stores whole 248-byte row runs per field at the segment's end instead of 16-32-row pieces per round
+#if defined(RG_EXPERIMENTS) && defined(RG_ROWWISE_NO_STAGE)
+  constexpr bool kStage = false;
+#else
+  constexpr bool kStage = kScatter;
+#endif
+  __shared__ __attribute__((aligned(16))) float stage_all[kStage ? kH : 1][kStage ? 64 * 8 : 4];
+
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   f32x2* rowacc = rowacc_all[kRegs ? 0 : wv];
+  float* const stage = stage_all[kStage ? wv : 0];
   // 26-bit weight mask in a VGPR the compiler cannot fold: (x & mask) | w_base is then ONE v_and_or_b32 (this ISA's VOP3
   // takes no literal, and a literal mask splits it into v_and + v_or)
   unsigned wmask = 0x3FFFFFFu;
@@ -1091,7 +1102,9 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
           if (j < (NP >> stages)) {                                 // wave-uniform
-            if constexpr (DIAG & 2) {      // timing-only: no output store
+            if constexpr (kStage) {
+              if (owner && f0 + j * lp < NF) stage[r.myrow * 8 + f0 + j * lp] = w[j] > 0.0f ? p[j] / w[j] : fill;
+            } else if constexpr (DIAG & 2) {      // timing-only: no output store
               if (owner && f0 + j * lp < NF && p[j] == 123.456f) dst[j * step_f] = w[j];
             } else {
               if (owner && f0 + j * lp < NF) dst[j * step_f] = w[j] > 0.0f ? p[j] / w[j] : fill;
@@ -1157,6 +1170,20 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+  if constexpr (kStage) {
+    if (span > 0 && lane < nrows) {                   // (the wave barrier above orders the rounds' LDS writes before these reads)
+      const f32x4 lo = reinterpret_cast<const f32x4*>(stage)[2 * lane], hi = reinterpret_cast<const f32x4*>(stage)[2 * lane + 1];
+      const float vals[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        if constexpr (DIAG & 2) {
+          if (vals[f] == 123.456f) out[(size_t)f * n_vox + r0 + lane] = vals[f];
+        } else {
+          out[(size_t)f * n_vox + r0 + lane] = vals[f];
+        }
+      }
+    }
+  }
   if (lane < nrows && !(kScatter && span > 0)) {     // kScatter: the rounds stored their rows; a segment without pairs has none
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
@@ -1229,7 +1256,8 @@ int launch_rowwise(int window_cap, const void* indptr, const int64_t* dict_ptr, 
   constexpr int STRIDE = stride_for(NF);
   constexpr int WS = rowwise_entry_words<NF>();                                   // 4-byte words per window entry
   const bool lds_sums = DIAG == 0 && rowwise_lds_rowsums(NF, window_cap);
-  const long kStatic = (RowwiseConfig<NF>::regs && !lds_sums) ? 16 : (long)kH * 64 * NF * 8;   // the row-sum array, if any
+  const long kStatic = NF >= 5 ? (long)kH * 64 * 8 * 4 + 16                                     // the staged values of 5-8 fields
+                               : (RowwiseConfig<NF>::regs && !lds_sums) ? 16 : (long)kH * 64 * NF * 8;   // the row-sum array, if any
   // one entry beyond window_cap: the sentinel; a smaller window only sends more chunks down the per-pair path
   const long room = (65536 - kStatic - 256) / (4 * WS) - 1;
   if (window_cap > room) window_cap = (int)room;
