@@ -8,7 +8,11 @@ answers or refuses.  What measurement scripts need beyond that lives ONLY in thi
     output store, no record loads, ...; rg_csr_compact_apply_f32 tile = 901..909; rg_csr_apply_f32_ex variant 28),
   * several chunks per workgroup (tile = 2200 + n), block-rotation overrides (tile + 1000 * rotation), K1 tuning variants,
   * the A/B knobs of the row-wise kernel (-DRG_ROWWISE_KPRE3= / _TARGET3= / _REGS3= / _WAVES1= / _WAVES3= / _SLOTS= /
-    _TWO_SELECTS, -DRG_FILL_BATCH=).
+    _TWO_SELECTS, -DRG_FILL_BATCH=; round 4: _BYTEMASK= (smallest field count with byte-mask entries), _MASK_UBYTE,
+    _KPRE8= / _TARGET8= / _REGS8= / _WAVES8= / _WSLOTS8= (five to eight fields), _SCATTER_MIN_NF= + _FENCE_MIN_NF=,
+    _NO_STAGE, _NO_FALLBACK (register-count probe), _PREFETCH= + _PREFETCH_MIN_NF= + _PREFETCH_HEAD= (touch loads)),
+  * timing-only ablations of the eight-field pass (tile = 2100 + 1 / 2 / 16 / 19 / 40 / 42 / 43 / 59) and the overlapping-streams
+    proxy of a denser record (tile = 2173).
 
     python tools/build_experiments.py [--tag NAME] [-DFLAG[=V] ...]      -> prints the path of the library
 
