@@ -556,7 +556,7 @@ __global__ RG_ROWWISE_BOUNDS void csr_compact_rowwise_kernel(
   static_assert(NF >= 1 && NF <= 8 && STRIDE == stride_for(NF), "passes of 1-8 fields");
   using Cfg = RowwiseConfig<NF>;
   constexpr int KPRE = Cfg::kpre;
-  // Record prefetch (experiment builds only; measured SLOWER, EXPERIMENTS.md R4.9): touch loads -- one dword per 64 bytes, never
+  // Record prefetch (experiment builds only; measured SLOWER, EXPERIMENTS.md R4.11): touch loads -- one dword per 64 bytes, never
   // read -- of the segment's first kPrefetchHead bytes before the window fill and, when round rho begins, of the records of round
   // rho + kPrefetch - 1, so that the real loads would hit in L2.
 #if defined(RG_EXPERIMENTS) && defined(RG_ROWWISE_PREFETCH)
