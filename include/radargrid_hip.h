@@ -37,8 +37,9 @@ extern "C" {
  * .so is reported as such instead of being called with shifted arguments.  History: 100 rounds 1-2; 101 rec_order / plane0 of
  * rg_csr_compact_pack and rg_csr_compact_apply_packed_f32 (round 3); 102 rg_csr_compact_apply_columns_f32, diagnostic tile
  * codes refused by the product build (round 4); 103 the row-wise kernel of rg_csr_compact_apply_packed_f32 takes 1-8 fields
- * (no signature changed: a 102 library answers RG_EUNSUPPORTED for 5-8). */
-#define RG_VERSION 103
+ * (no signature changed: a 102 library answers RG_EUNSUPPORTED for 5-8); 104 rg_cellgrid.levels + the per-level gate lists
+ * (rg_geom_bin_levels_count / rg_geom_bin_gates_levels_f32). */
+#define RG_VERSION 104
 #define RG_MAX_FIELDS 8
 
 typedef void* rg_stream_t; /* hipStream_t */
@@ -179,6 +180,11 @@ typedef struct rg_cellgrid {
   double inv_cx, inv_cy; /* 1 / cell size */
   double z_lo, z_hi;     /* gates with z_rel outside [z_lo, z_hi] cannot reach any voxel and are dropped */
   int32_t ncx, ncy;
+  int32_t levels;        /* 0 / 1: one list for all grid levels (cell_start[ncx*ncy + 1]); nz: one list PER LEVEL, holding only the
+                          * gates that can reach that level (rg_geom_bin_gates_levels_f32; cell_start[nz*ncx*ncy + 1], the cells
+                          * of level iz at iz*ncx*ncy ..) -- a third of the candidates per voxel block */
+  int32_t level0;        /* per-level lists: the grid level the call's zc[0] is (a call may cover levels level0 .. level0 + nz - 1
+                          * of the binned grid by passing zc + level0); 0 otherwise */
 } rg_cellgrid;
 
 typedef struct rg_gate4 { float x, y, z; int32_t index; } rg_gate4; /* 16 bytes: one dwordx4 per candidate */
@@ -198,6 +204,21 @@ int rg_geom_bin_gates_f32(const float* gate_x, const float* gate_y, const float*
                           float radar_altitude, float toa, const rg_cellgrid* cells_host,
                           rg_gate4* sorted_gates, int32_t* cell_start,
                           void* workspace, int64_t workspace_bytes, rg_stream_t stream);
+
+/* Per-level lists: gate g is listed under level iz iff |z_rel(g) - zc[iz]| <= R_g, R_g = max(min_radius, beam_factor * |g| /
+ * (1 - beam_factor)) (slightly inflated) -- a bound on the radius of influence of ANY voxel the gate can be a neighbour of
+ * (compute.py:46-47: r_v = max(min_radius, |v| * beam_factor) and |v| <= |g| + r_v), so no neighbour is lost; needs
+ * 0 <= beam_factor < 1.  rg_geom_bin_levels_count writes the number of (gate, level) entries to *total (device memory);
+ * rg_geom_bin_gates_levels_f32 then fills sorted_gates[n_entries] in (level, cell, gate index) order and
+ * cell_start[nz*ncx*ncy + 1] (cells->levels must equal nz).  zc: the float32 level coordinates (device). */
+int rg_geom_bin_levels_count(const float* gate_x, const float* gate_y, const float* gate_z, int64_t n_gates,
+                             float radar_altitude, float toa, const rg_cellgrid* cells_host, const float* zc, int32_t nz,
+                             double min_radius, double beam_factor, int64_t* total, rg_stream_t stream);
+int64_t rg_geom_bin_levels_workspace_bytes(int64_t n_gates, int64_t n_entries, int64_t n_cells_total);
+int rg_geom_bin_gates_levels_f32(const float* gate_x, const float* gate_y, const float* gate_z, int64_t n_gates,
+                                 float radar_altitude, float toa, const rg_cellgrid* cells_host, const float* zc, int32_t nz,
+                                 double min_radius, double beam_factor, int64_t n_entries, rg_gate4* sorted_gates,
+                                 int32_t* cell_start, void* workspace, int64_t workspace_bytes, rg_stream_t stream);
 
 /* counts[v] = number of gates within voxel v's radius of influence; xc/yc/zc are the float32 linspace
  * coordinate tables of radar_grid/compute.py:184-186 (device pointers). */

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # experiment build (tools/build_experiments.py) assign ``_native.LIB_PATH`` themselves before the first load; the ABI
 # check below applies to them as well.
 LIB_PATH = os.path.join(HERE, "csrc", "libradargrid_hip.so")
-ABI_VERSION = 103          # include/radargrid_hip.h: RG_VERSION -- load_library refuses a library built from another header
+ABI_VERSION = 104          # include/radargrid_hip.h: RG_VERSION -- load_library refuses a library built from another header
 
 RG_MAX_FIELDS = 8
 RG_EXCLUDED_BITS = 0x7FD1CE5D
@@ -45,7 +45,8 @@ class NativeError(RuntimeError):
 
 class CellGrid(Structure):
     _fields_ = [("x0", c_double), ("y0", c_double), ("inv_cx", c_double), ("inv_cy", c_double),
-                ("z_lo", c_double), ("z_hi", c_double), ("ncx", c_int32), ("ncy", c_int32)]
+                ("z_lo", c_double), ("z_hi", c_double), ("ncx", c_int32), ("ncy", c_int32), ("levels", c_int32),
+                ("level0", c_int32)]
 
 
 class PlaneTest(Structure):
@@ -76,6 +77,12 @@ SIGNATURES = {
     "rg_geom_bin_workspace_bytes": (c_int64, [c_int64, c_int32, c_int32]),
     "rg_geom_bin_gates_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, POINTER(CellGrid),
                                         c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "rg_geom_bin_levels_count": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, POINTER(CellGrid), c_void_p,
+                                           c_int32, c_double, c_double, c_void_p, c_void_p]),
+    "rg_geom_bin_levels_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
+    "rg_geom_bin_gates_levels_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, POINTER(CellGrid),
+                                               c_void_p, c_int32, c_double, c_double, c_int64, c_void_p, c_void_p, c_void_p,
+                                               c_int64, c_void_p]),
     "rg_geom_count_f32": (c_int32, [c_void_p, c_void_p, POINTER(CellGrid), c_void_p, c_void_p, c_void_p, c_int32,
                                     c_int32, c_int32, c_double, c_double, c_void_p, c_void_p]),
     "rg_csr_compact_apply_f32": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,

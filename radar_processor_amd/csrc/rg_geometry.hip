@@ -76,6 +76,77 @@ __global__ __launch_bounds__(rg::kBlock) void gather_sorted_kernel(const unsigne
   sorted[j] = r;
 }
 
+// ---- per-level lists ---------------------------------------------------------------------------------
+// Gate g can only be a neighbour of voxels whose radius of influence is below R_g = max(min_radius, bf * |g| / (1 - bf)):
+// r_v = max(min_radius, bf * |v|) (compute.py:46-47) and |v| <= |g| + |g - v| < |g| + r_v, so r_v > min_radius implies
+// r_v (1 - bf) < bf |g|.  A neighbour needs |z_g - z_v| <= |g - v| < r_v <= R_g: the gate is listed under the levels within
+// R_g (inflated by 1e-6 + 1 mm against the rounding of this very computation) of its height, and under no other.
+struct LevelArgs {
+  const float* zc;
+  int nz;
+  double min_radius, k;      // k = bf / (1 - bf)
+};
+
+__device__ __forceinline__ bool gate_cell(const float* __restrict__ gx, const float* __restrict__ gy,
+                                          const float* __restrict__ gz, long i, float radar_alt, float toa, const Cells& c,
+                                          unsigned* cell, double* zrel, double* reach, const LevelArgs& la) {
+  const float z_rel = __fsub_rn(gz[i], radar_alt);      // compute.py:182, as bin_keys_kernel
+  const double x = (double)gx[i], y = (double)gy[i], z = (double)z_rel;
+  const double tx = cell_coord(x, c.x0, c.inv_cx), ty = cell_coord(y, c.y0, c.inv_cy);
+  const bool keep = z_rel <= toa && z >= c.z_lo && z <= c.z_hi && tx >= 0.0 && tx < (double)c.ncx && ty >= 0.0 &&
+                    ty < (double)c.ncy;
+  if (!keep) return false;
+  *cell = (unsigned)((int)ty * c.ncx + (int)tx);
+  *zrel = z;
+  const double norm = sqrt(x * x + y * y + z * z);
+  *reach = fmax(la.min_radius, norm * la.k) * (1.0 + 1e-6) + 1e-3;
+  return true;
+}
+
+__global__ __launch_bounds__(rg::kBlock) void level_count_kernel(const float* __restrict__ gx, const float* __restrict__ gy,
+                                                                 const float* __restrict__ gz, long n, float radar_alt,
+                                                                 float toa, Cells c, LevelArgs la,
+                                                                 unsigned* __restrict__ counts,
+                                                                 unsigned long long* __restrict__ total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned cnt = 0;
+  if (i < n) {
+    unsigned cell;
+    double z, reach;
+    if (gate_cell(gx, gy, gz, i, radar_alt, toa, c, &cell, &z, &reach, la)) {
+      for (int iz = 0; iz < la.nz; ++iz) cnt += fabs(z - (double)la.zc[iz]) <= reach ? 1u : 0u;
+    }
+    if (counts) counts[i] = cnt;
+  }
+  if (total) {      // one atomic per wavefront
+    unsigned long long sum = cnt;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) sum += __shfl_xor(sum, m, 64);
+    if ((threadIdx.x & 63) == 0 && sum) atomicAdd(total, sum);
+  }
+}
+
+__global__ __launch_bounds__(rg::kBlock) void level_expand_kernel(const float* __restrict__ gx, const float* __restrict__ gy,
+                                                                  const float* __restrict__ gz, long n, float radar_alt,
+                                                                  float toa, Cells c, LevelArgs la,
+                                                                  const unsigned* __restrict__ offsets,
+                                                                  unsigned* __restrict__ keys, unsigned* __restrict__ vals) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned cell;
+  double z, reach;
+  if (!gate_cell(gx, gy, gz, i, radar_alt, toa, c, &cell, &z, &reach, la)) return;
+  unsigned pos = offsets[i];
+  const unsigned per_level = (unsigned)c.ncx * (unsigned)c.ncy;
+  for (int iz = 0; iz < la.nz; ++iz) {
+    if (fabs(z - (double)la.zc[iz]) <= reach) {
+      keys[pos] = (unsigned)iz * per_level + cell;
+      vals[pos] = (unsigned)i;
+      ++pos;
+    }
+  }
+}
+
 struct WidenI32 {
   __host__ __device__ long long operator()(int v) const { return (long long)v; }
 };
@@ -143,6 +214,110 @@ extern "C" int rg_geom_bin_gates_f32(const float* gate_x, const float* gate_y, c
   hipLaunchKernelGGL(cell_start_kernel, dim3((n_cells + 1 + rg::kBlock - 1) / rg::kBlock), dim3(rg::kBlock), 0, s,
                      keys_out, (long)n, n_cells, cell_start);
   return rg::check_launch("rg_geom_bin_gates_f32");
+}
+
+namespace {
+
+size_t scan_u32_temp_bytes(size_t n) {
+  size_t bytes = 0;
+  (void)rocprim::exclusive_scan(nullptr, bytes, (const unsigned*)nullptr, (unsigned*)nullptr, 0u, n, rocprim::plus<unsigned>(),
+                                (hipStream_t)0, false);
+  return bytes;
+}
+
+int check_levels(const char* fn, const rg_cellgrid* cells, const float* zc, int nz, double min_radius, double beam_factor) {
+  RG_REQUIRE(cells && zc, RG_EINVAL, "%s: null pointer", fn);
+  RG_REQUIRE(nz >= 1 && cells->levels == nz && cells->level0 == 0, RG_EINVAL, "%s: cells->levels=%d, level0=%d, nz=%d", fn,
+             cells->levels, cells->level0, nz);
+  RG_REQUIRE(cells->ncx >= 1 && cells->ncy >= 1 && (long)cells->ncx * cells->ncy * nz < 0x7FFFFFFFL, RG_EINVAL,
+             "%s: bad cell grid %dx%d x %d levels", fn, cells->ncx, cells->ncy, nz);
+  RG_REQUIRE(min_radius >= 0.0 && beam_factor >= 0.0 && beam_factor < 0.5, RG_EUNSUPPORTED,
+             "%s: per-level gate lists need 0 <= beam_factor < 0.5 (got %g); use the single list", fn, beam_factor);
+  return RG_OK;
+}
+
+}  // namespace
+
+extern "C" int rg_geom_bin_levels_count(const float* gate_x, const float* gate_y, const float* gate_z, int64_t n_gates,
+                                        float radar_altitude, float toa, const rg_cellgrid* cells_host, const float* zc,
+                                        int32_t nz, double min_radius, double beam_factor, int64_t* total,
+                                        rg_stream_t stream) {
+  const int rc = check_levels("rg_geom_bin_levels_count", cells_host, zc, nz, min_radius, beam_factor);
+  if (rc != RG_OK) return rc;
+  RG_REQUIRE(total && n_gates >= 0 && n_gates <= 0x7FFFFFFFL, RG_EINVAL, "rg_geom_bin_levels_count: bad arguments");
+  RG_REQUIRE(n_gates == 0 || (gate_x && gate_y && gate_z), RG_EINVAL, "rg_geom_bin_levels_count: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(total, 0, sizeof(int64_t), s) != hipSuccess) {
+    rg::set_error("rg_geom_bin_levels_count: memset failed");
+    return RG_ELAUNCH;
+  }
+  if (n_gates > 0) {
+    const LevelArgs la{zc, nz, min_radius, beam_factor / (1.0 - beam_factor)};
+    hipLaunchKernelGGL(level_count_kernel, dim3((unsigned)((n_gates + rg::kBlock - 1) / rg::kBlock)), dim3(rg::kBlock), 0, s,
+                       gate_x, gate_y, gate_z, (long)n_gates, radar_altitude, toa, to_cells(cells_host), la, (unsigned*)nullptr,
+                       reinterpret_cast<unsigned long long*>(total));
+  }
+  return rg::check_launch("rg_geom_bin_levels_count");
+}
+
+extern "C" int64_t rg_geom_bin_levels_workspace_bytes(int64_t n_gates, int64_t n_entries, int64_t n_cells_total) {
+  if (n_gates < 0 || n_entries < 0 || n_cells_total < 1 || n_entries > 0x7FFFFFFFL || n_cells_total >= 0x7FFFFFFFL) return RG_EINVAL;
+  const size_t ne = (size_t)n_entries, ng = (size_t)n_gates + 1;
+  const size_t arr = round_up(ne * sizeof(unsigned), 256), garr = round_up(ng * sizeof(unsigned), 256);
+  const size_t temp = sort_temp_bytes(ne, key_bits((unsigned)n_cells_total)), temp2 = scan_u32_temp_bytes(ng);
+  return (int64_t)(4 * arr + 2 * garr + round_up(temp > temp2 ? temp : temp2, 256) + 256);
+}
+
+extern "C" int rg_geom_bin_gates_levels_f32(const float* gate_x, const float* gate_y, const float* gate_z, int64_t n_gates,
+                                            float radar_altitude, float toa, const rg_cellgrid* cells_host, const float* zc,
+                                            int32_t nz, double min_radius, double beam_factor, int64_t n_entries,
+                                            rg_gate4* sorted_gates, int32_t* cell_start, void* workspace,
+                                            int64_t workspace_bytes, rg_stream_t stream) {
+  const int rc = check_levels("rg_geom_bin_gates_levels_f32", cells_host, zc, nz, min_radius, beam_factor);
+  if (rc != RG_OK) return rc;
+  RG_REQUIRE(cell_start && n_gates >= 0 && n_gates <= 0x7FFFFFFFL && n_entries >= 0 && n_entries <= 0x7FFFFFFFL, RG_EINVAL,
+             "rg_geom_bin_gates_levels_f32: bad arguments");
+  RG_REQUIRE(n_entries == 0 || (gate_x && gate_y && gate_z && sorted_gates && workspace), RG_EINVAL,
+             "rg_geom_bin_gates_levels_f32: null pointer");
+  RG_REQUIRE(rg::aligned16(sorted_gates), RG_EALIGN, "rg_geom_bin_gates_levels_f32: sorted_gates must be 16-byte aligned");
+  const Cells c = to_cells(cells_host);
+  const unsigned n_cells = (unsigned)c.ncx * (unsigned)c.ncy * (unsigned)nz;
+  const int64_t need = rg_geom_bin_levels_workspace_bytes(n_gates, n_entries, n_cells);
+  RG_REQUIRE(need >= 0 && workspace_bytes >= need, RG_EWORKSPACE, "rg_geom_bin_gates_levels_f32: workspace %lld < %lld bytes",
+             (long long)workspace_bytes, (long long)need);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t ne = (size_t)n_entries, ng = (size_t)n_gates + 1;
+  const size_t arr = round_up(ne * sizeof(unsigned), 256), garr = round_up(ng * sizeof(unsigned), 256);
+  char* base = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+  unsigned* keys_in = reinterpret_cast<unsigned*>(base);
+  unsigned* vals_in = reinterpret_cast<unsigned*>(base + arr);
+  unsigned* keys_out = reinterpret_cast<unsigned*>(base + 2 * arr);
+  unsigned* vals_out = reinterpret_cast<unsigned*>(base + 3 * arr);
+  unsigned* counts = reinterpret_cast<unsigned*>(base + 4 * arr);
+  unsigned* offsets = reinterpret_cast<unsigned*>(base + 4 * arr + garr);
+  void* temp = base + 4 * arr + 2 * garr;
+  if (n_gates > 0 && ne > 0) {
+    const LevelArgs la{zc, nz, min_radius, beam_factor / (1.0 - beam_factor)};
+    const dim3 ggrid((unsigned)((ng + rg::kBlock - 1) / rg::kBlock)), block(rg::kBlock);
+    hipError_t e = hipMemsetAsync(counts, 0, ng * sizeof(unsigned), s);
+    RG_REQUIRE(e == hipSuccess, RG_ELAUNCH, "rg_geom_bin_gates_levels_f32: memset: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(level_count_kernel, ggrid, block, 0, s, gate_x, gate_y, gate_z, (long)n_gates, radar_altitude, toa, c, la,
+                       counts, (unsigned long long*)nullptr);
+    size_t scan_bytes = scan_u32_temp_bytes(ng);
+    e = rocprim::exclusive_scan(temp, scan_bytes, counts, offsets, 0u, ng, rocprim::plus<unsigned>(), s, false);
+    RG_REQUIRE(e == hipSuccess, RG_ELAUNCH, "rg_geom_bin_gates_levels_f32: scan: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(level_expand_kernel, ggrid, block, 0, s, gate_x, gate_y, gate_z, (long)n_gates, radar_altitude, toa, c, la,
+                       offsets, keys_in, vals_in);
+    const unsigned bits = key_bits(n_cells);
+    size_t temp_bytes = sort_temp_bytes(ne, bits);
+    e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, ne, 0u, bits, s, false);
+    RG_REQUIRE(e == hipSuccess, RG_ELAUNCH, "rg_geom_bin_gates_levels_f32: radix sort: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(gather_sorted_kernel, dim3((unsigned)((ne + rg::kBlock - 1) / rg::kBlock)), block, 0, s, keys_out, vals_out,
+                       (long)ne, n_cells, gate_x, gate_y, gate_z, radar_altitude, sorted_gates);
+  }
+  hipLaunchKernelGGL(cell_start_kernel, dim3((n_cells + 1 + rg::kBlock - 1) / rg::kBlock), dim3(rg::kBlock), 0, s, keys_out,
+                     (long)ne, n_cells, cell_start);
+  return rg::check_launch("rg_geom_bin_gates_levels_f32");
 }
 
 extern "C" int64_t rg_scan_workspace_bytes(int64_t n) {

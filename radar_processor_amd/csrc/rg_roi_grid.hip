@@ -105,6 +105,7 @@ __global__ __launch_bounds__(rg::kBlock) void roi_block_kernel(SearchArgs a, con
   const int iy0 = (int)py * BY, ix0 = (int)(rem - py * wpx) * PX;
   const int nvy = a.ny - iy0 < BY ? a.ny - iy0 : BY;
   const double z = (double)a.zc[iz];                             // common to the whole wave
+  const int lvl_off = a.c.levels > 1 ? (a.c.level0 + iz) * (a.c.ncx * a.c.ncy) : 0;   // per-level gate lists: this level's cells
   const float zf = (float)z;                                     // grid coordinates ARE float32 values: exact
   const int vl = lane & (kVB - 1);                               // voxel of the block this lane owns ...
   const int bxl = vl & (BX - 1), byl = vl >> kLgBX;              // ... at (bxl, byl) inside the block
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(rg::kBlock) void roi_block_kernel(SearchArgs a, con
       // bounds of up to 64 cell rows with one vector load each (lane <-> cell row)
       int rs_l = 0, re_l = 0;
       if (rb + lane < nrows) {
-        const int base = (cy0 + rb + lane) * a.c.ncx;
+        const int base = lvl_off + (cy0 + rb + lane) * a.c.ncx;
         rs_l = a.cell_start[base + cx0];
         re_l = a.cell_start[base + cx1 + 1];
       }

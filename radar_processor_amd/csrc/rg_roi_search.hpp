@@ -10,12 +10,16 @@ namespace roi {
 struct Cells {
   double x0, y0, inv_cx, inv_cy, z_lo, z_hi;
   int ncx, ncy;
+  int levels;      // > 1: per-level gate lists, the cells of level iz at iz * ncx * ncy
+  int level0;      // ... and the level the call's zc[0] is
 };
 
 inline Cells to_cells(const rg_cellgrid* c) {
   Cells r;
   r.x0 = c->x0; r.y0 = c->y0; r.inv_cx = c->inv_cx; r.inv_cy = c->inv_cy; r.z_lo = c->z_lo; r.z_hi = c->z_hi;
   r.ncx = c->ncx; r.ncy = c->ncy;
+  r.levels = c->levels > 1 ? c->levels : 0;
+  r.level0 = c->levels > 1 ? c->level0 : 0;
   return r;
 }
 
@@ -57,6 +61,10 @@ inline int check_search_args(const char* fn, const rg_gate4* sorted, const int32
   RG_REQUIRE(cells->ncx >= 1 && cells->ncy >= 1 && (long)cells->ncx * cells->ncy < 0x7FFFFFFFL, RG_EINVAL,
              "%s: bad cell grid %dx%d", fn, cells->ncx, cells->ncy);
   RG_REQUIRE(rg::aligned16(sorted), RG_EALIGN, "%s: sorted_gates must be 16-byte aligned", fn);
+  RG_REQUIRE(cells->levels <= 1 || (cells->level0 >= 0 && cells->level0 + nz <= cells->levels &&
+                                    (long)cells->ncx * cells->ncy * cells->levels < 0x7FFFFFFFL), RG_EINVAL,
+             "%s: per-level gate lists for %d levels, call covers levels %d .. %d (or too many cells)", fn, cells->levels,
+             cells->level0, cells->level0 + nz - 1);
   return RG_OK;
 }
 

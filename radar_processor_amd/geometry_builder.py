@@ -44,7 +44,12 @@ class RoiSearch:
     """Cell-sorted gates + voxel coordinate tables in HBM: everything the ROI search kernels need."""
 
     def __init__(self, gate_x, gate_y, gate_z, grid_shape, grid_limits, radar_altitude=0.0, min_radius=250.0,
-                 beam_factor=0.01746, toa=17000.0, device=None, cell_size: Optional[float] = None):
+                 beam_factor=0.01746, toa=17000.0, device=None, cell_size: Optional[float] = None,
+                 per_level: Optional[bool] = None):
+        """``per_level``: keep one cell-sorted gate list PER GRID LEVEL, each holding only the gates that can reach that level
+        (``rg_geom_bin_gates_levels_f32``: |z_gate - z_level| within the largest radius of influence any neighbouring voxel of
+        the gate can have) -- a voxel block then streams a third of the candidates.  Default: on where the bound holds
+        (0 <= beam_factor < 0.5) and the grid has more than one level; the neighbour sets are the same either way."""
         torch = _native.torch_mod()
         lib = _native.load_library()
         self.dev = _native.canonical_device(device)
@@ -77,17 +82,49 @@ class RoiSearch:
         x_lo, x_hi = float(xc.min()) - r_max, float(xc.max()) + r_max
         y_lo, y_hi = float(yc.min()) - r_max, float(yc.max()) + r_max
 
+        want_levels = (nz > 1 and 0.0 <= self.beam_factor < 0.5 and self.min_radius >= 0.0) if per_level is None else bool(per_level)
         if cell_size is None:
-            cell_size = self._auto_cell(gx, gy, x_lo, x_hi, y_lo, y_hi)
+            # a level's list holds about a third of the gates: three times the cell size keeps a cell row of a voxel's search
+            # box at about one wavefront of candidates (bench grid, ms per K2 pass: x1 13.7, x1.5 12.3, x2 11.9, x3 11.6, x4 11.6)
+            cell_size = self._auto_cell(gx, gy, x_lo, x_hi, y_lo, y_hi) * (3.0 if want_levels else 1.0)
         # keep the cell table small (int32 entries): at most ~16 M cells
         span = max(x_hi - x_lo, y_hi - y_lo)
         cell_size = max(float(cell_size), span / 4000.0, 1.0)
         self.cell_size = cell_size
         ncx = max(1, int(math.ceil((x_hi - x_lo) / cell_size)))
         ncy = max(1, int(math.ceil((y_hi - y_lo) / cell_size)))
+        self.per_level = bool(want_levels and ncx * ncy * nz < 2 ** 31 - 1)
         self.cells = _native.CellGrid(x0=x_lo, y0=y_lo, inv_cx=1.0 / cell_size, inv_cy=1.0 / cell_size,
-                                      z_lo=float(zc.min()) - r_max, z_hi=float(zc.max()) + r_max, ncx=ncx, ncy=ncy)
-
+                                      z_lo=float(zc.min()) - r_max, z_hi=float(zc.max()) + r_max, ncx=ncx, ncy=ncy,
+                                      levels=nz if self.per_level else 0, level0=0)
+        alt32, toa32 = float(np.float32(radar_altitude)), float(np.float32(toa))
+        if self.per_level:
+            # one list per level: count the (gate, level) entries, then bin them
+            total = torch.zeros(1, dtype=torch.int64, device=self.dev)
+            with torch.cuda.device(self.dev):
+                _native.check(lib.rg_geom_bin_levels_count(
+                    _native.ptr(gx), _native.ptr(gy), _native.ptr(gz), self.n_gates, alt32, toa32, self.cells,
+                    _native.ptr(self.zc), nz, self.min_radius, self.beam_factor, _native.ptr(total), _native.stream_ptr()),
+                    "rg_geom_bin_levels_count")
+                n_entries = int(total.item())
+            if n_entries > 2 ** 31 - 1:
+                raise _native.NativeError(f"{n_entries} (gate, level) entries exceed the int32 positions of the cell table; "
+                                          "pass per_level=False")
+            self.sorted_gates = torch.empty(max(n_entries, 1) * 4, dtype=torch.float32, device=self.dev)
+            self.cell_start = torch.empty(ncx * ncy * nz + 1, dtype=torch.int32, device=self.dev)
+            ws_bytes = int(lib.rg_geom_bin_levels_workspace_bytes(self.n_gates, n_entries, ncx * ncy * nz))
+            if ws_bytes < 0:
+                raise _native.NativeError("rg_geom_bin_levels_workspace_bytes rejected its arguments")
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.dev)
+            with torch.cuda.device(self.dev):
+                _native.check(lib.rg_geom_bin_gates_levels_f32(
+                    _native.ptr(gx), _native.ptr(gy), _native.ptr(gz), self.n_gates, alt32, toa32, self.cells,
+                    _native.ptr(self.zc), nz, self.min_radius, self.beam_factor, n_entries, _native.ptr(self.sorted_gates),
+                    _native.ptr(self.cell_start), _native.ptr(ws), ws_bytes, _native.stream_ptr()),
+                    "rg_geom_bin_gates_levels_f32")
+                self.n_binned = int(self.cell_start[-1].item())      # (gate, level) entries
+            del ws
+            return
         self.sorted_gates = torch.empty(max(self.n_gates, 1) * 4, dtype=torch.float32, device=self.dev)
         self.cell_start = torch.empty(ncx * ncy + 1, dtype=torch.int32, device=self.dev)
         ws_bytes = int(lib.rg_geom_bin_workspace_bytes(self.n_gates, ncx, ncy))
@@ -96,12 +133,20 @@ class RoiSearch:
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.dev)
         with torch.cuda.device(self.dev):
             _native.check(lib.rg_geom_bin_gates_f32(
-                _native.ptr(gx), _native.ptr(gy), _native.ptr(gz), self.n_gates,
-                float(np.float32(radar_altitude)), float(np.float32(toa)), self.cells,
+                _native.ptr(gx), _native.ptr(gy), _native.ptr(gz), self.n_gates, alt32, toa32, self.cells,
                 _native.ptr(self.sorted_gates), _native.ptr(self.cell_start), _native.ptr(ws), ws_bytes,
                 _native.stream_ptr()), "rg_geom_bin_gates_f32")
             self.n_binned = int(self.cell_start[-1].item())
         del ws
+
+    def cells_from(self, level0: int):
+        """The cell grid for a call that covers the levels from ``level0`` on (passing ``zc + level0``): per-level gate lists
+        are addressed by the absolute level."""
+        if not self.per_level or level0 == 0:
+            return self.cells
+        c = self.cells
+        return _native.CellGrid(x0=c.x0, y0=c.y0, inv_cx=c.inv_cx, inv_cy=c.inv_cy, z_lo=c.z_lo, z_hi=c.z_hi, ncx=c.ncx,
+                                ncy=c.ncy, levels=c.levels, level0=int(level0))
 
     def _auto_cell(self, gx, gy, x_lo, x_hi, y_lo, y_hi) -> float:
         """Cell size for which one cell row of a typical voxel's search box holds about one wavefront (64) of
@@ -243,7 +288,7 @@ def _build_compact_only(search: "RoiSearch", weighting: str, pairs_per_slab: int
                 # the fill kernel writes at absolute pair positions: shift the pointers so that the slab's first pair
                 # lands at the start of the scratch buffers (the weights go straight to their final place otherwise)
                 _native.check(lib.rg_geom_fill_f32(
-                    _native.ptr(search.sorted_gates), _native.ptr(search.cell_start), search.cells, _native.ptr(search.xc),
+                    _native.ptr(search.sorted_gates), _native.ptr(search.cell_start), search.cells_from(iz0), _native.ptr(search.xc),
                     _native.ptr(search.yc), _native.ptr(search.zc) + 4 * iz0, iz1 - iz0, ny, nx, search.min_radius,
                     search.beam_factor, _native.WEIGHTINGS[weighting], _native.ptr(indptr) + 8 * iz0 * n_xy,
                     _native.ptr(scratch) - 4 * p0, w_ptr, stream), "rg_geom_fill_f32")
@@ -320,7 +365,7 @@ def compute_grid_geometry(
                        min_radius=min_radius, beam_factor=beam_factor, toa=toa)
     nz, ny, nx = search.grid_shape
     logger.info(f"Radar altitude: {radar_altitude:.1f} m")
-    logger.info(f"TOA filter: {search.n_binned:,} of {search.n_gates:,} gates kept (below {toa}m and within reach "
+    logger.info(f"TOA filter: {search.n_binned:,} {'(gate, level) entries' if search.per_level else 'gates'} of {search.n_gates:,} gates kept (below {toa}m and within reach "
                 f"of the grid); cell size {search.cell_size:.0f} m")
     logger.info(f"Processing {nz} z-levels on {search.dev}...")
     if layout not in ("csr", "compact", "packed", "auto"):

@@ -161,7 +161,9 @@ def test_c4_fused_gridder_invariants():
     filled = torch.isfinite(out[0])
     frac = float(filled.float().mean())
     assert 0.6 < frac < 0.9
-    assert float((out[0][filled] + 3.5).abs().max()) <= 3.5 * 2e-6
+    # a constant field comes back as the constant up to the rounding of two float32 sums of up to ~10^4 positive terms per lane
+    # (measured worst case 2.04e-6 relative with the per-level gate lists' order, 1.9e-6 with the single list's; parity bar: 1e-5)
+    assert float((out[0][filled] + 3.5).abs().max()) <= 3.5 * 4e-6
     assert bool((torch.isfinite(out[1]) <= filled).all())
     valid = dbz[(msk == 0) & torch.isfinite(dbz)]
     seen = out[1][torch.isfinite(out[1])]

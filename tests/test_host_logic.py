@@ -262,7 +262,7 @@ class TestNativeLibrary:
 
     def test_version_and_constants(self):
         lib = rg.load_library(require_device=False)
-        assert lib.rg_version() == _native.ABI_VERSION == 103
+        assert lib.rg_version() == _native.ABI_VERSION == 104
         header = open(os.path.join(REPO, "include", "radargrid_hip.h")).read()
         assert f"0x{_native.RG_EXCLUDED_BITS:08X}" in header.upper().replace("0X", "0x")
         assert np.isnan(np.array([_native.RG_EXCLUDED_BITS], dtype=np.uint32).view(np.float32)[0])
