@@ -6,7 +6,8 @@
 // Bound: NOT HBM (compulsory traffic is only the sorted gates + packed fields + the output grid); the kernel is
 // limited by VALU issue, mostly in the dense stage (about 21 VALU instructions per 64 (record, voxel) tests).
 //
-// Structure (one wavefront = a 32 x 2 patch of one grid level, processed as 4 blocks of 8 x 2 = 16 voxels):
+// Structure (one wavefront = a 16 x 4 patch of one grid level, processed as 4 blocks of 4 x 4 = 16 voxels; the candidates come
+// from the level's OWN cell-sorted gate list when the search structure keeps one per level -- rg_geom_bin_gates_levels_f32):
 //   * voxel blocking: neighbouring voxels (240 m apart, ROI >= 250 m) share almost all candidates, so every gate
 //     record is loaded ONCE per 16-voxel block.  The chain cell_start -> gate record that made the first version
 //     latency-bound is broken by loading the bounds of all cell rows of the block with one vector load and by
@@ -67,6 +68,10 @@ __device__ __forceinline__ float weight_from_f32(float d2f, float r2f, float inv
 // Count and fill classify hits with the same code, so the second pass writes exactly what the first one counted; a
 // voxel's hits arrive in (cell row, sorted position) order, the row order the CSR has always had.
 constexpr int kGridMode = 0, kCountMode = 1, kFillMode = 2;
+#if !defined(RG_EXPERIMENTS) || !defined(RG_K2_BX)
+#undef RG_K2_BX
+#define RG_K2_BX 4            // block shape BX x (16 / BX) voxels; experiment builds: -DRG_K2_BX=8 / 16
+#endif
 
 // BX x BY = 16 voxels per block (BY rows of BX consecutive voxels); a wavefront walks 4 blocks side by side in x.
 template <int MODE, int W, int NF, int STRIDE, int BX>
@@ -357,8 +362,10 @@ inline dim3 k2_grid(const SearchArgs& a) {
 
 template <int W, int NF, int STRIDE>
 int launch(const SearchArgs& a, const float* packed, float fill, float* out, hipStream_t s) {
-  // block shape 8 x 2: measured 16.0 ms on the bench grid against 16.5 (4 x 4) and 19.4 (16 x 1)
-  hipLaunchKernelGGL((roi_block_kernel<kGridMode, W, NF, STRIDE, 8>), k2_grid<8>(a), dim3(rg::kBlock), 0, s, a, packed, fill,
+  // block shape: with one gate list for all levels 8 x 2 measured best (16.0 ms on the bench grid against 16.5 for 4 x 4 and 19.4
+  // for 16 x 1); with the per-level lists, whose candidate stage is a third as long, the more compact 4 x 4 block (fewer survivors
+  // per block) wins: 11.1 against 11.6 ms
+  hipLaunchKernelGGL((roi_block_kernel<kGridMode, W, NF, STRIDE, RG_K2_BX>), k2_grid<RG_K2_BX>(a), dim3(rg::kBlock), 0, s, a, packed, fill,
                      out, (int*)nullptr, (const long long*)nullptr, (int*)nullptr, (float*)nullptr);
   return rg::check_launch("rg_roi_grid_f32");
 }
@@ -395,7 +402,9 @@ extern "C" int rg_roi_grid_f32(const rg_gate4* sorted_gates, const int32_t* cell
   RG_REQUIRE(stride == stride_for(n_fields), RG_EINVAL, "rg_roi_grid_f32: stride=%d, expected %d for %d fields", stride,
              stride_for(n_fields), n_fields);
   RG_REQUIRE(rg::aligned16(packed), RG_EALIGN, "rg_roi_grid_f32: packed must be 16-byte aligned");
-  RG_REQUIRE((long)nx * ny * nz > 0 && (long)((nx + 31) / 32) * ((ny + 1) / 2) * nz < 0xFFFFFFF0L, RG_EUNSUPPORTED,
+  RG_REQUIRE((long)nx * ny * nz > 0 &&
+                 (long)((nx + 4 * RG_K2_BX - 1) / (4 * RG_K2_BX)) * ((ny + 16 / RG_K2_BX - 1) / (16 / RG_K2_BX)) * nz < 0xFFFFFFF0L,
+             RG_EUNSUPPORTED,
              "rg_roi_grid_f32: grid too large for one launch");
   const SearchArgs a = make_args(sorted_gates, cell_start, cells_host, xc, yc, zc, nz, ny, nx, min_radius, beam_factor);
   hipStream_t s = (hipStream_t)stream;
@@ -418,7 +427,7 @@ extern "C" int rg_geom_count_f32(const rg_gate4* sorted_gates, const int32_t* ce
   if (rc != RG_OK) return rc;
   RG_REQUIRE(counts, RG_EINVAL, "rg_geom_count_f32: null counts");
   const SearchArgs a = make_args(sorted_gates, cell_start, cells_host, xc, yc, zc, nz, ny, nx, min_radius, beam_factor);
-  hipLaunchKernelGGL((roi_block_kernel<kCountMode, RG_W_NEAREST, 1, 1, 8>), k2_grid<8>(a), dim3(rg::kBlock), 0,
+  hipLaunchKernelGGL((roi_block_kernel<kCountMode, RG_W_NEAREST, 1, 1, RG_K2_BX>), k2_grid<RG_K2_BX>(a), dim3(rg::kBlock), 0,
                      (hipStream_t)stream, a, (const float*)nullptr, 0.0f, (float*)nullptr, counts,
                      (const long long*)nullptr, (int*)nullptr, (float*)nullptr);
   return rg::check_launch("rg_geom_count_f32");
@@ -434,11 +443,11 @@ extern "C" int rg_geom_fill_f32(const rg_gate4* sorted_gates, const int32_t* cel
   RG_REQUIRE(weighting >= RG_W_BARNES2 && weighting <= RG_W_NEAREST, RG_EINVAL, "rg_geom_fill_f32: unknown weighting %d",
              weighting);
   const SearchArgs a = make_args(sorted_gates, cell_start, cells_host, xc, yc, zc, nz, ny, nx, min_radius, beam_factor);
-  const dim3 grid = k2_grid<8>(a), block(rg::kBlock);
+  const dim3 grid = k2_grid<RG_K2_BX>(a), block(rg::kBlock);
   hipStream_t s = (hipStream_t)stream;
   const long long* ip = reinterpret_cast<const long long*>(indptr);
 #define RG_FILL(W_)                                                                                                     \
-  hipLaunchKernelGGL((roi_block_kernel<kFillMode, W_, 1, 1, 8>), grid, block, 0, s, a, (const float*)nullptr, 0.0f,     \
+  hipLaunchKernelGGL((roi_block_kernel<kFillMode, W_, 1, 1, RG_K2_BX>), grid, block, 0, s, a, (const float*)nullptr, 0.0f,     \
                      (float*)nullptr, (int*)nullptr, ip, gate_idx, weights)
   switch (weighting) {
     case RG_W_BARNES2: RG_FILL(RG_W_BARNES2); break;

@@ -21,7 +21,7 @@ def main():
     dev = torch.device("cuda", 0)
     cfg = synthetic.CONFIGS["METRIC"]
     vol = synthetic.make_volume(cfg["n_elev"], cfg["n_az"], cfg["n_gates"], seed=0, fields=("DBZH",))
-    search = rg.RoiSearch(vol.gate_x, vol.gate_y, vol.gate_z, cfg["grid_shape"], cfg["grid_limits"], device=dev)
+    search = rg.RoiSearch(vol.gate_x, vol.gate_y, vol.gate_z, cfg["grid_shape"], cfg["grid_limits"], device=dev)   # (built by the in-tree library)
     f = torch.from_numpy(np.ascontiguousarray(np.ma.getdata(vol.fields["DBZH"]))).to(dev)
     m = torch.from_numpy(np.ma.getmaskarray(vol.fields["DBZH"]).astype(np.uint8)).to(dev)
     out = torch.empty((1, *cfg["grid_shape"]), dtype=torch.float32, device=dev)
