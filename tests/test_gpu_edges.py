@@ -670,3 +670,44 @@ def test_device_layout_sidecar_round_trip(rg, tmp_path):
     other = rg.compute_grid_geometry(gx, gy, gz, shape, limits, str(tmp_path), min_radius=700.0, beam_factor=0.05)
     assert rg.load_device_layout(other, side) is False                      # another CSR: key mismatch
     assert rg.load_device_layout(back, str(tmp_path / "missing.npz")) is False
+
+
+@pytest.mark.parametrize("weighting", ["barnes2", "nearest"])
+def test_per_level_gate_lists_give_the_same_geometry(rg, weighting):
+    """RoiSearch keeps one cell-sorted gate list per grid level (a gate under the levels within the largest radius of influence
+    any neighbouring voxel can have) -- a candidate filter, nothing else: against the single list for all levels the builder returns
+    the same rows (same gates, same float32 weights) for every voxel, whatever the cell size, a non-zero radar altitude and
+    a min_radius that dominates included; the CSR-free gridder agrees to float32 rounding; a slab of levels addresses its lists
+    through cells_from(level0); beam factors the bound does not cover fall back to the single list."""
+    import torch
+    from radar_processor_amd import synthetic
+    from radar_processor_amd.roi_grid import roi_grid_fields_device
+    dev = torch.device("cuda", 0)
+    vol = synthetic.make_volume(n_elev=7, n_az=120, n_gates=240, seed=5, fields=("DBZH",))
+    shape, limits = (9, 37, 41), ((0.0, 12000.0), (-70e3, 70e3), (-60e3, 80e3))
+    f = torch.from_numpy(np.ascontiguousarray(np.ma.getdata(vol.fields["DBZH"]))).to(dev)
+    m = torch.from_numpy(np.ma.getmaskarray(vol.fields["DBZH"]).astype(np.uint8)).to(dev)
+    for kw in (dict(), dict(radar_altitude=350.0, min_radius=2500.0), dict(beam_factor=0.05, toa=9000.0)):
+        ref = rg.RoiSearch(vol.gate_x, vol.gate_y, vol.gate_z, shape, limits, device=dev, per_level=False, **kw)
+        assert not ref.per_level
+        want = ref.build_csr(weighting)
+        w_ip, w_idx, w_w = oracle.canonical_rows(want.indptr.cpu().numpy(), want.gate_indices.cpu().numpy(),
+                                                 want.weights.cpu().numpy())
+        grid_ref = roi_grid_fields_device(ref, [f], [m], weighting=weighting)
+        for cell in (None, 900.0, 7000.0):
+            s = rg.RoiSearch(vol.gate_x, vol.gate_y, vol.gate_z, shape, limits, device=dev, cell_size=cell, **kw)
+            assert s.per_level and s.cells.levels == shape[0] and s.n_binned > ref.n_binned
+            assert s.count_pairs() == want.n_pairs
+            got = s.build_csr(weighting)
+            g_ip, g_idx, g_w = oracle.canonical_rows(got.indptr.cpu().numpy(), got.gate_indices.cpu().numpy(),
+                                                     got.weights.cpu().numpy())
+            np.testing.assert_array_equal(g_ip, w_ip)
+            np.testing.assert_array_equal(g_idx, w_idx)
+            np.testing.assert_array_equal(g_w.view(np.int32), w_w.view(np.int32))
+            grid = roi_grid_fields_device(s, [f], [m], weighting=weighting)
+            assert_same_to_rounding(grid, grid_ref, scale=80.0)
+            assert s.cells_from(0) is s.cells and s.cells_from(4).level0 == 4 and s.cells_from(4).levels == shape[0]
+    wide = rg.RoiSearch(vol.gate_x, vol.gate_y, vol.gate_z, shape, limits, device=dev, beam_factor=0.7)
+    assert not wide.per_level and wide.cells.levels == 0
+    with pytest.raises(rg.NativeError, match="beam_factor"):
+        rg.RoiSearch(vol.gate_x, vol.gate_y, vol.gate_z, shape, limits, device=dev, beam_factor=0.7, per_level=True)

@@ -282,6 +282,22 @@ class TestNativeLibrary:
         assert lib.rg_gate_mask_f32(1 << 12, 8, 99, 0.0, 0.0, 1 << 12, None) == _native.RG_EINVAL
         assert lib.rg_geom_bin_workspace_bytes(-1, 4, 4) == _native.RG_EINVAL
         assert lib.rg_geom_bin_workspace_bytes(1000, 4, 4) > 4 * 1000 * 4
+        # per-level gate lists: the level count must be the grid's, the reach bound needs 0 <= beam_factor < 0.5
+        assert lib.rg_geom_bin_levels_workspace_bytes(-1, 10, 16) == _native.RG_EINVAL
+        assert lib.rg_geom_bin_levels_workspace_bytes(1000, 9000, 5 * 16) > 4 * 9000 * 4
+        cells = _native.CellGrid(x0=0.0, y0=0.0, inv_cx=1.0, inv_cy=1.0, z_lo=0.0, z_hi=1.0, ncx=4, ncy=4, levels=5, level0=0)
+        args = (1 << 12, 1 << 12, 1 << 12, 10, 0.0, 1.0, cells, 1 << 12)
+        assert lib.rg_geom_bin_levels_count(*args, 4, 250.0, 0.01746, 1 << 12, None) == _native.RG_EINVAL        # 4 levels != 5
+        assert lib.rg_geom_bin_levels_count(*args, 5, 250.0, 0.6, 1 << 12, None) == _native.RG_EUNSUPPORTED
+        assert b"beam_factor" in lib.rg_last_error()
+        assert lib.rg_geom_bin_levels_count(*args, 5, 250.0, 0.01746, None, None) == _native.RG_EINVAL          # no total
+        cells.level0 = 2                                                    # a slab view is for the search kernels only
+        assert lib.rg_geom_bin_gates_levels_f32(*args, 5, 250.0, 0.01746, 10, 1 << 12, 1 << 12, 1 << 12, 1 << 20,
+                                                None) == _native.RG_EINVAL
+        # the search kernels check that a slab of levels lies inside the binned levels
+        cells.level0 = 3
+        assert lib.rg_geom_count_f32(1 << 12, 1 << 12, cells, 1 << 12, 1 << 12, 1 << 12, 3, 4, 4, 250.0, 0.01746, 1 << 12,
+                                     None) == _native.RG_EINVAL and b"levels 3 .. 5" in lib.rg_last_error()
 
     def test_product_library_refuses_experiment_codes(self):
         """Timing-only kernels (results wrong by construction) and tuning variants are not in the shipped library: their
