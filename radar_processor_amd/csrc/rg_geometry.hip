@@ -12,6 +12,10 @@
 // has to test are a provable superset of its ROI ball: cell_coord() is monotone in the coordinate, so a
 // gate with x - r <= gx <= x + r lies in a cell between cell(x - r) and cell(x + r).
 //
+// One such list serves all grid levels (rg_geom_bin_gates_f32), or -- the default of the Python layer -- every level gets its OWN
+// list holding only the gates that can reach it (rg_geom_bin_gates_levels_f32, see LevelArgs below): the search kernels then
+// stream a third of the candidates.
+//
 // This file holds the binning (bucket + stable radix sort + cell table) and the prefix sum of the row lengths; the
 // count / fill passes over the voxels run on the voxel-blocked search kernel of rg_roi_grid.hip, shared with the
 // fused gridder.  A row comes out in (cell row, sorted position) order -- deterministic, no atomics.
