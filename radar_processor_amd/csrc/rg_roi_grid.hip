@@ -91,9 +91,12 @@ __global__ __launch_bounds__(rg::kBlock) void roi_block_kernel(SearchArgs a, con
   // round trip into every dense step).  With 4 or 8 slots the ring would cost 4-8 KiB more LDS per wavefront and an
   // unconditional 16-32 byte LDS read per lane and step -- measured 35 % slower than gathering per hit, which stays.
   constexpr bool VRING = GRID && STRIDE <= 2;
+  // one field, weighted modes: the value takes the place of the gate index in the queued record (the index is needed by the
+  // builder and by the closest-gate tie-break only), so the dense stage reads ONE 16-byte LDS entry per record
+  constexpr bool VPACK = VRING && STRIDE == 1 && W != RG_W_CLOSEST;
   constexpr int kRing = VRING ? kRingGrid : kRingBuild;
   __shared__ rg_gate4 ring_all[rg::kBlock / rg::kWave][kRing];
-  __shared__ float ringv_all[rg::kBlock / rg::kWave][VRING ? kRing * STRIDE : 1];
+  __shared__ float ringv_all[rg::kBlock / rg::kWave][(VRING && !VPACK) ? kRing * STRIDE : 1];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   rg_gate4* ring = ring_all[wv];
@@ -173,7 +176,8 @@ __global__ __launch_bounds__(rg::kBlock) void roi_block_kernel(SearchArgs a, con
       for (int f = 0; f < STRIDE; ++f) val_nx[f] = 0.0f;
       if constexpr (VRING) {
         g_nx = ring[(head + slot) & (kRing - 1)];
-        load_packed<STRIDE>(ringv, (unsigned)((head + slot) & (kRing - 1)), val_nx);
+        if constexpr (VPACK) val_nx[0] = __builtin_bit_cast(float, g_nx.index);
+        else load_packed<STRIDE>(ringv, (unsigned)((head + slot) & (kRing - 1)), val_nx);
       }
       for (int e0 = 0; e0 < n; e0 += kSlots) {
         const int e = e0 + slot;
@@ -186,7 +190,8 @@ __global__ __launch_bounds__(rg::kBlock) void roi_block_kernel(SearchArgs a, con
         if constexpr (VRING) {
           if (e0 + kSlots < n) {
             g_nx = ring[(head + e + kSlots) & (kRing - 1)];
-            load_packed<STRIDE>(ringv, (unsigned)((head + e + kSlots) & (kRing - 1)), val_nx);
+            if constexpr (VPACK) val_nx[0] = __builtin_bit_cast(float, g_nx.index);
+            else load_packed<STRIDE>(ringv, (unsigned)((head + e + kSlots) & (kRing - 1)), val_nx);
           }
           const float dx = g.x - xf, dy = g.y - yf, dz = g.z - zf;
           d2f = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
@@ -248,8 +253,12 @@ __global__ __launch_bounds__(rg::kBlock) void roi_block_kernel(SearchArgs a, con
     for (int f = 0; f < STRIDE; ++f) pend_val[f] = 0.0f;
     auto flush_pending = [&]() {
       if (pend) {
+        if constexpr (VPACK) {
+          ring[pend_pos].index = __builtin_bit_cast(int, pend_val[0]);
+        } else {
 #pragma unroll
-        for (int f = 0; f < STRIDE; ++f) ringv[pend_pos * STRIDE + f] = pend_val[f];
+          for (int f = 0; f < STRIDE; ++f) ringv[pend_pos * STRIDE + f] = pend_val[f];
+        }
       }
       pend = false;
       ready = tail;
