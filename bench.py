@@ -68,7 +68,7 @@ def parse_args(argv=None):
                          "volume, then rg_column_reduce_f32 / rg_cappi_lerp_f32 on the stored grids; fused = the gridding kernel's "
                          "products epilogue (column mode, no 3-D grid in HBM: the memory-saving way, about as fast); auto = what "
                          "batch.VolumeBatch does for products=PlaneProducts (separate: measured at least as fast)")
-    ap.add_argument("--settle-tries", type=int, default=3,
+    ap.add_argument("--settle-tries", type=int, default=4,
                     help="csr mode, packed records: placements of the record array tried during the (untimed) geometry build -- the "
                          "fastest under a 3-launch probe of the gridding kernel is kept (CsrGridder.settle_records); 1 = off. "
                          "Reported in config.records_settled")
