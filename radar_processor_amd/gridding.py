@@ -283,7 +283,7 @@ class CsrGridder:
         not run."""
         torch = _native.torch_mod()
         c = self.compact
-        if not self.has_columns_kernel or tries <= 1 or c.rec is None or c.rec.numel() == 0:
+        if c is None or not self.packed_stream or tries <= 1 or c.rec is None or c.rec.numel() == 0:
             return None
         nbytes = int(c.rec.numel()) * c.rec.element_size()
         free_b, _ = torch.cuda.mem_get_info(self.dev)
