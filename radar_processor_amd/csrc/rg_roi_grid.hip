@@ -167,6 +167,10 @@ __global__ __launch_bounds__(rg::kBlock) void roi_block_kernel(SearchArgs a, con
     const unsigned long long lower_slots = vox_lanes & ((1ull << (16 * slot)) - 1ull);
 
     auto dense = [&](int n) {  // test n queued records against the block's 16 voxels, 4 records per step
+#if defined(RG_EXPERIMENTS) && defined(RG_K2_ABL) && RG_K2_ABL == 1     // timing-only (tools/exp_k2_breakdown.py): the dense stage
+      head += n;                                                        // does nothing -- what is left is the candidate side
+      return;
+#endif
       // value-ring variant: the next step's record and field slots are read from LDS before this step's arithmetic,
       // so the LDS latency overlaps it; slots past n hold stale but addressable ring entries and are ignored
       rg_gate4 g_nx;

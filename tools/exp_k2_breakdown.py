@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""K2 (rg_roi_grid_f32) on the bench grid: the shipped kernel against two timing-only builds (tools/build_experiments.py
--DRG_K2_ABL=1: the dense stage does nothing; =2: no candidate survives the block filter, i.e. candidate streaming + filter alone).
-usage: exp_k2_breakdown.py name=lib.so ..."""
+"""K2 (rg_roi_grid_f32) on the bench grid: the shipped kernel against other builds of the library loaded next to it -- the
+timing-only build whose dense stage does nothing (tools/build_experiments.py --tag k2a1 -DRG_K2_ABL=1: what is left is the
+candidate side) and other block shapes (-DRG_K2_BX=8 / 16).  usage: exp_k2_breakdown.py name=lib.so ..."""
 import ctypes
 import json
 import os
